@@ -1,0 +1,172 @@
+// gecm_curve.hpp — Montgomery-curve XZ point arithmetic and the stage-1 tape interpreter.
+//
+// Replaces, for the GPU, the reference's L1 layer:
+//   vec_add        ecm.c:407-443   (4 mul + 2 sqr + 1 addsub)
+//   vec_duplicate  ecm.c:445-457   (3 mul + 2 sqr + 1 sub + 1 add)
+//   prac           ecm.c:565-884   (rules 3,4,5,9 of Montgomery's Table 4; ORIG_PRAC undefined)
+//   ecm_stage1     ecm.c:1806-1854
+// The sequence of field operations per point operation is exactly the reference's, so every
+// intermediate is the same element of Z/N (projective X,Z are not normalised, so the formula
+// sequence matters — SURVEY.md §8a).
+//
+// All lanes of all waves execute the same chain for the same B1, so the host walks
+// ecm_stage1/prac ONCE and emits a byte tape (gecm_tape.h); the kernel is an interpreter whose
+// control flow is wave-uniform (tape byte -> SGPR -> s_cbranch), with the three live points
+// A=pt1, B=pt2, C=pt3 of prac() resident in VGPRs for the whole stage.  The reference's pointer
+// swaps (ecm.c:624-629, 704-711) become register renames at the end of each tape step.
+#pragma once
+#include "gecm_field.hpp"
+#include "gecm_tape.h"
+
+template <int NL>
+struct Pt {
+    Fe<NL> X, Z;
+};
+
+// Pout = P1 + P2 given sums/differences of P1 and P2 and the difference point Pd.
+// ecm.c:417-440: U = d1*s2, V = s1*d2, X+ = Zd*(U+V)^2, Z+ = Xd*(U-V)^2
+template <int NL>
+__device__ __forceinline__ void pt_add(Pt<NL> &out, const Fe<NL> &s1, const Fe<NL> &d1, const Fe<NL> &s2,
+                                       const Fe<NL> &d2, const Pt<NL> &pd, const ModK<NL> &m)
+{
+    Fe<NL> u, v, p, q;
+    fe_mul(u, d1, s2, m);   // U
+    fe_mul(v, s1, d2, m);   // V
+    fe_add(p, u, v);        // U + V
+    fe_sub(q, u, v, m);     // U - V
+    fe_sqr(p, p, m);        // (U+V)^2
+    fe_sqr(q, q, m);        // (U-V)^2
+    Fe<NL> x, z;
+    fe_mul(x, p, pd.Z, m);  // Z- * (U+V)^2
+    fe_mul(z, q, pd.X, m);  // X- * (U-V)^2
+    out.X = x;
+    out.Z = z;
+}
+
+// P = 2*(point whose sum/diff are s, d).  ecm.c:447-454.
+template <int NL>
+__device__ __forceinline__ void pt_dup(Pt<NL> &out, const Fe<NL> &s, const Fe<NL> &d, const Fe<NL> &s4,
+                                       const ModK<NL> &m)
+{
+    Fe<NL> t1, t2, t3;
+    fe_sqr(t1, d, m);        // V = (x-z)^2
+    fe_sqr(t2, s, m);        // U = (x+z)^2
+    fe_mul(out.X, t1, t2, m);  // X = U*V
+    fe_sub(t3, t2, t1, m);   // w = U - V
+    fe_mul(t2, t3, s4, m);   // t = (A+2)/4 * w
+    fe_add(t2, t2, t1);      // t = t + V
+    fe_mul(out.Z, t2, t3, m);  // Z = t*w
+}
+
+template <int NL>
+__device__ __forceinline__ void pt_sumdiff(Fe<NL> &s, Fe<NL> &d, const Pt<NL> &p, const ModK<NL> &m)
+{
+    fe_add(s, p.X, p.Z);
+    fe_sub(d, p.X, p.Z, m);
+}
+
+// First half of pt_add: pp = (U+V)^2, mm = (U-V)^2  (ecm.c:417-422)
+template <int NL>
+__device__ __forceinline__ void pt_add_uv(Fe<NL> &pp, Fe<NL> &mm, const Fe<NL> &s1, const Fe<NL> &d1,
+                                          const Fe<NL> &s2, const Fe<NL> &d2, const ModK<NL> &m)
+{
+    Fe<NL> u, v;
+    fe_mul(u, d1, s2, m);   // U
+    fe_mul(v, s1, d2, m);   // V
+    fe_add(pp, u, v);       // U + V
+    fe_sub(mm, u, v, m);    // U - V
+    fe_sqr(pp, pp, m);      // (U+V)^2
+    fe_sqr(mm, mm, m);      // (U-V)^2
+}
+
+// Run a tape on point P (held in A).  Returns with the result in A.
+//
+// The loop body contains exactly ONE inlined point addition and ONE inlined doubling (~55 KB of
+// straight-line code at NL=15, inside the 64 KB instruction cache); each tape op selects their
+// operands and destinations with wave-uniform branches and register moves (<2% of a step).
+// Register budget (<=256 VGPRs for 2 waves/SIMD): the difference point is only copied after
+// the first half of the addition, and s = (A+2)/4 is re-read from memory for each doubling
+// (doublings are ~10% of the steps) instead of occupying NL registers throughout.
+template <int NL>
+__device__ __forceinline__ void run_tape(const uint32_t *__restrict__ tape, uint32_t tape_len, Pt<NL> &A,
+                                         const uint32_t *__restrict__ S, size_t stride, size_t idx,
+                                         const ModK<NL> &m)
+{
+    Pt<NL> B = A, C = A;
+    for (uint32_t pc = 0; pc < tape_len; pc++) {
+        uint32_t w = tape[pc >> 2];
+        uint32_t op = __builtin_amdgcn_readfirstlane((w >> ((pc & 3u) * 8u)) & 0xffu);
+        if (op == GECM_OP_NOP) continue;
+        uint32_t rule = op & GECM_OP_RULE_MASK;
+        Fe<NL> s1, d1, s2, d2;
+        bool is_step = op >= GECM_OP_STEP;
+        bool do_add = is_step || op == GECM_OP_PRAC_END;
+        bool do_dup = (is_step && rule != GECM_OP_RULE3) || op == GECM_OP_PRAC_BEGIN;
+        if (is_step) {
+            if (op & GECM_OP_SWAP) {   // ecm.c:617-630
+                Pt<NL> t = A;
+                A = B;
+                B = t;
+            }
+            if (rule == GECM_OP_RULE3 || rule == GECM_OP_RULE4) {
+                // ecm.c:688-691 / 718-721: (s1,d1)<-B, (s2,d2)<-A, difference C
+                pt_sumdiff(s1, d1, B, m);
+                pt_sumdiff(s2, d2, A, m);
+            } else if (rule == GECM_OP_RULE5) {
+                // ecm.c:732-735: (s1,d1)<-C, (s2,d2)<-A, difference B
+                pt_sumdiff(s1, d1, C, m);
+                pt_sumdiff(s2, d2, A, m);
+            } else {
+                // rule 9, ecm.c:857-860: (s1,d1)<-C, (s2,d2)<-B, difference A
+                pt_sumdiff(s1, d1, C, m);
+                pt_sumdiff(s2, d2, B, m);
+            }
+        } else if (op == GECM_OP_PRAC_BEGIN) {
+            // ecm.c:603-613 (and the 2-power loop ecm.c:1817-1821)
+            B = A;
+            C = A;
+            pt_sumdiff(s2, d2, A, m);
+        } else {
+            // PRAC_END, ecm.c:868-873: (s1,d1)<-A, (s2,d2)<-B, difference C
+            pt_sumdiff(s1, d1, A, m);
+            pt_sumdiff(s2, d2, B, m);
+        }
+        Pt<NL> T, D;
+        if (do_add) {
+            Fe<NL> pp, mm, pd;
+            pt_add_uv(pp, mm, s1, d1, s2, d2, m);
+            bool pd_b = is_step && rule == GECM_OP_RULE5, pd_a = is_step && rule == GECM_OP_RULE9;
+            if (pd_b) pd = B.Z; else if (pd_a) pd = A.Z; else pd = C.Z;
+            fe_mul(T.X, pp, pd, m);    // Z- * (U+V)^2   ecm.c:438
+            if (pd_b) pd = B.X; else if (pd_a) pd = A.X; else pd = C.X;
+            fe_mul(T.Z, mm, pd, m);    // X- * (U-V)^2   ecm.c:439
+        }
+        if (do_dup) {
+            // (s2,d2) again from the point being doubled (unchanged so far): cheaper than
+            // keeping them live across the addition.
+            Fe<NL> s, d, s4;
+            if (is_step && rule == GECM_OP_RULE9) pt_sumdiff(s, d, B, m); else pt_sumdiff(s, d, A, m);
+            fe_load(s4, S, stride, idx);
+            pt_dup(D, s, d, s4, m);
+        }
+        if (is_step) {
+            if (rule == GECM_OP_RULE3) {        // (B,T,C) <- (T,C,B)   ecm.c:704-711
+                C = B;
+                B = T;
+            } else if (rule == GECM_OP_RULE4) { // B = T; A = 2A
+                B = T;
+                A = D;
+            } else if (rule == GECM_OP_RULE5) { // C = T; A = 2A
+                C = T;
+                A = D;
+            } else {                             // C = T; B = 2B
+                C = T;
+                B = D;
+            }
+        } else if (op == GECM_OP_PRAC_BEGIN) {
+            A = D;
+        } else {
+            A = T;
+        }
+    }
+}

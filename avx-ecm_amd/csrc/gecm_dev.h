@@ -1,0 +1,54 @@
+/* gecm_dev.h — internal device layer (HIP side) of libgecm.  Plain C interface so that the
+ * host logic (C, gcc) never sees HIP types.  Not part of the public ABI (that is include/gecm.h).
+ *
+ * All residues crossing this layer are NL limbs of 28 bits in uint32_t, struct-of-arrays
+ * [limb][curve] (curve index fastest: consecutive lanes of a wavefront read consecutive words),
+ * in the engine's internal Montgomery form (R = 2^(28*NL)) unless a function says otherwise.
+ */
+#ifndef GECM_DEV_H
+#define GECM_DEV_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gecm_dev gecm_dev;
+
+enum { GECM_L0_MUL = 0, GECM_L0_SQR = 1, GECM_L0_ADD = 2, GECM_L0_SUB = 3, GECM_L0_ADDSUB = 4 };
+
+int gecm_dev_count(void);
+const char *gecm_dev_error(void);
+/* limb counts for which kernels are instantiated, ascending, 0-terminated */
+const int *gecm_dev_supported_nl(void);
+
+int gecm_dev_open(gecm_dev **out, int device, int nl, const uint32_t *n, const uint32_t *kp,
+                  const uint32_t *one, uint32_t rho);
+void gecm_dev_close(gecm_dev *d);
+int gecm_dev_device_name(gecm_dev *d, char *buf, size_t len);
+
+/* (re)allocate state for ncurves curves: X, Z, S (+ scratch for downloads) */
+int gecm_dev_resize(gecm_dev *d, size_t ncurves);
+size_t gecm_dev_stride(gecm_dev *d);
+int gecm_dev_upload(gecm_dev *d, const uint32_t *X, const uint32_t *Z, const uint32_t *S);
+int gecm_dev_set_tape(gecm_dev *d, const uint8_t *tape, size_t len);
+/* stage 1: asynchronous on the context's stream; HIP events bracket the kernel */
+int gecm_dev_stage1(gecm_dev *d);
+int gecm_dev_sync(gecm_dev *d);
+float gecm_dev_last_kernel_ms(gecm_dev *d);
+/* canonical Montgomery-form X, Z (what P holds after ecm_stage1 in the reference, modulo R) */
+int gecm_dev_download_mont(gecm_dev *d, uint32_t *X, uint32_t *Z);
+/* canonical de-Montgomeryised x, z (the reference's X*1, Z*1 of ecm.c:1327-1331) */
+int gecm_dev_download_plain(gecm_dev *d, uint32_t *x, uint32_t *z);
+
+/* test-level L0 operators on `count` independent residues.  Inputs canonical (< N), internal
+ * Montgomery form; outputs canonical.  For MUL/SQR the product is additionally multiplied by
+ * the constant `fix` (internal Montgomery form; pass `one` for none): this is how the public
+ * ABI returns results in the reference's own Montgomery radix. */
+int gecm_dev_l0(gecm_dev *d, int op, const uint32_t *a, const uint32_t *b, uint32_t *c, uint32_t *dd,
+                size_t count, const uint32_t *fix);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,127 @@
+// gecm_kernels.hip — HIP kernels of libgecm for ONE limb count (compile with -DGECM_NL=<n>).
+// One translation unit per limb count so the (large, fully unrolled) kernels build in parallel.
+// See gecm_field.hpp / gecm_curve.hpp for the arithmetic; DESIGN.md for the layout.
+#include "gecm_dev.h"
+#include "gecm_launch.h"
+#include "gecm_curve.hpp"
+#include <hip/hip_runtime.h>
+
+#ifndef GECM_NL
+#error "compile with -DGECM_NL=<limbs>"
+#endif
+
+template <int NL>
+struct ModArgs {
+    ModK<NL> m;
+    Fe<NL> one;   // R mod N, canonical
+};
+// ---------------------------------------------------------------- stage 1
+// One curve per lane.  64-thread blocks (one wave): a CU holds 8 of them at 2 waves/SIMD, the
+// occupancy at which v_mad_u64_u32 issues back-to-back (profiles/r01_valu_ubench_gfx950.txt).
+template <int NL>
+__global__ void __launch_bounds__(64, 2)
+k_stage1(const uint32_t *__restrict__ tape, uint32_t tape_len, uint32_t *__restrict__ X,
+         uint32_t *__restrict__ Z, const uint32_t *__restrict__ S, size_t stride, ModArgs<NL> a)
+{
+    size_t idx = (size_t)blockIdx.x * 64 + threadIdx.x;
+    Pt<NL> P;
+    fe_load(P.X, X, stride, idx);
+    fe_load(P.Z, Z, stride, idx);
+    run_tape<NL>(tape, tape_len, P, S, stride, idx, a.m);
+    Fe<NL> ox, oz;
+    fe_canonical_mont(ox, P.X, a.one, a.m);
+    fe_canonical_mont(oz, P.Z, a.one, a.m);
+    fe_store(X, stride, idx, ox);
+    fe_store(Z, stride, idx, oz);
+}
+
+template <int NL>
+__global__ void __launch_bounds__(64)
+k_from_mont(const uint32_t *__restrict__ X, const uint32_t *__restrict__ Z, uint32_t *__restrict__ ox,
+            uint32_t *__restrict__ oz, size_t stride, ModArgs<NL> a)
+{
+    size_t idx = (size_t)blockIdx.x * 64 + threadIdx.x;
+    Fe<NL> x, z, r;
+    fe_load(x, X, stride, idx);
+    fe_load(z, Z, stride, idx);
+    fe_from_mont_canonical(r, x, a.m);
+    fe_store(ox, stride, idx, r);
+    fe_from_mont_canonical(r, z, a.m);
+    fe_store(oz, stride, idx, r);
+}
+
+// ---------------------------------------------------------------- L0 test-level operators
+template <int NL>
+__global__ void __launch_bounds__(64)
+k_l0(int op, const uint32_t *__restrict__ A, const uint32_t *__restrict__ B, uint32_t *__restrict__ C,
+     uint32_t *__restrict__ D, size_t stride, ModArgs<NL> a, Fe<NL> fix)
+{
+    size_t idx = (size_t)blockIdx.x * 64 + threadIdx.x;
+    Fe<NL> x, y, r, t;
+    fe_load(x, A, stride, idx);
+    fe_load(y, B, stride, idx);
+    if (op == GECM_L0_MUL) {
+        fe_mul(t, x, y, a.m);
+        fe_canonical_mont(r, t, fix, a.m);
+        fe_store(C, stride, idx, r);
+    } else if (op == GECM_L0_SQR) {
+        fe_sqr(t, x, a.m);
+        fe_canonical_mont(r, t, fix, a.m);
+        fe_store(C, stride, idx, r);
+    } else {
+        if (op == GECM_L0_ADD || op == GECM_L0_ADDSUB) {
+            fe_add(t, x, y);
+            fe_canonical_mont(r, t, a.one, a.m);
+            fe_store(C, stride, idx, r);
+        }
+        if (op == GECM_L0_SUB || op == GECM_L0_ADDSUB) {
+            fe_sub(t, x, y, a.m);
+            fe_canonical_mont(r, t, a.one, a.m);
+            fe_store(op == GECM_L0_SUB ? C : D, stride, idx, r);
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------- launchers (C linkage)
+template <int NL>
+static ModArgs<NL> make_args(const gecm_modconst *mc)
+{
+    ModArgs<NL> a;
+    for (int i = 0; i < NL; i++) {
+        a.m.n[i] = mc->n[i];
+        a.m.kp[i] = mc->kp[i];
+        a.one.v[i] = mc->one[i];
+    }
+    a.m.rho = mc->rho;
+    return a;
+}
+
+#define CAT_(a, b) a##b
+#define CAT(a, b) CAT_(a, b)
+
+extern "C" void CAT(gecm_launch_stage1_, GECM_NL)(void *stream, const gecm_modconst *mc, const uint32_t *tape,
+                                                   uint32_t tape_len, uint32_t *X, uint32_t *Z,
+                                                   const uint32_t *S, size_t stride)
+{
+    hipLaunchKernelGGL(k_stage1<GECM_NL>, dim3((unsigned)(stride / 64)), dim3(64), 0, (hipStream_t)stream, tape,
+                       tape_len, X, Z, S, stride, make_args<GECM_NL>(mc));
+}
+
+extern "C" void CAT(gecm_launch_from_mont_, GECM_NL)(void *stream, const gecm_modconst *mc, const uint32_t *X,
+                                                      const uint32_t *Z, uint32_t *ox, uint32_t *oz,
+                                                      size_t stride)
+{
+    hipLaunchKernelGGL(k_from_mont<GECM_NL>, dim3((unsigned)(stride / 64)), dim3(64), 0, (hipStream_t)stream, X, Z,
+                       ox, oz, stride, make_args<GECM_NL>(mc));
+}
+
+extern "C" void CAT(gecm_launch_l0_, GECM_NL)(void *stream, const gecm_modconst *mc, int op, const uint32_t *A,
+                                               const uint32_t *B, uint32_t *C, uint32_t *D, size_t stride,
+                                               const uint32_t *fix)
+{
+    Fe<GECM_NL> f;
+    for (int i = 0; i < GECM_NL; i++) f.v[i] = fix[i];
+    hipLaunchKernelGGL(k_l0<GECM_NL>, dim3((unsigned)(stride / 64)), dim3(64), 0, (hipStream_t)stream, op, A, B, C,
+                       D, stride, make_args<GECM_NL>(mc), f);
+}

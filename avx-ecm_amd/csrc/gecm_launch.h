@@ -1,0 +1,33 @@
+/* gecm_launch.h — per-limb-count kernel launchers (one object file per GECM_NL). */
+#ifndef GECM_LAUNCH_H
+#define GECM_LAUNCH_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* limb counts built into the library; keep in sync with the Makefile's NLS */
+#define GECM_NL_LIST(X) X(8) X(12) X(15) X(19) X(23) X(26) X(30) X(34) X(37)
+
+typedef struct {
+    const uint32_t *n, *kp, *one;
+    uint32_t rho;
+} gecm_modconst;
+
+#define GECM_DECL(nl)                                                                                     \
+    void gecm_launch_stage1_##nl(void *stream, const gecm_modconst *mc, const uint32_t *tape,             \
+                                 uint32_t tape_len, uint32_t *X, uint32_t *Z, const uint32_t *S,          \
+                                 size_t stride);                                                          \
+    void gecm_launch_from_mont_##nl(void *stream, const gecm_modconst *mc, const uint32_t *X,             \
+                                    const uint32_t *Z, uint32_t *ox, uint32_t *oz, size_t stride);        \
+    void gecm_launch_l0_##nl(void *stream, const gecm_modconst *mc, int op, const uint32_t *A,            \
+                             const uint32_t *B, uint32_t *C, uint32_t *D, size_t stride,                  \
+                             const uint32_t *fix);
+GECM_NL_LIST(GECM_DECL)
+#undef GECM_DECL
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,527 @@
+/* gecm_api.c — public C ABI of libgecm (include/gecm.h): host logic in C above the HIP device
+ * layer (csrc/gecm_dev.h).  Mirrors the reference's setup and phase functions:
+ *   Montgomery constants        main.c:597-640
+ *   NWORDS/MAXBITS rule         main.c:465-483
+ *   build_one_curve             ecm.c:1548-1803
+ *   ecm_stage1                  ecm.c:1806-1854 (tape built by gecm_plan.c, run by the device)
+ *   save line / check_factor    ecm.c:1319-1388, 2542-2557
+ */
+#include "../../include/gecm.h"
+#include "../csrc/gecm_dev.h"
+#include "gecm_plan.h"
+#include "mpl.h"
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define LIMB_BITS 28
+
+static __thread char g_err[512];
+static void set_err(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+const char *gecm_last_error(void) { return g_err; }
+const char *gecm_version(void) { return "libgecm 0.1 (gfx950)"; }
+int gecm_device_count(void) { return gecm_dev_count(); }
+
+struct gecm_ctx {
+    int device, digitbits, nwords, maxbits, nbits, nl;
+    mpl_t N;
+    mpl_t rref_mod_n;    /* 2^(digitbits*nwords) mod N  = the reference's "one" */
+    mpl_t rint_mod_n;    /* 2^(28*nl) mod N */
+    mpl_t ref_to_int;    /* Rint * Rref^-1 mod N : x*Rref -> x*Rint by plain modular multiply */
+    mpl_t int_to_ref;    /* Rref * Rint^-1 mod N */
+    uint64_t rho_ref;
+    uint32_t rho28;
+    uint32_t *n28, *kp28, *one28, *fix28; /* fix28 = Rint^2/Rref mod N (see gecm_dev_l0) */
+    gecm_dev *dev, *dev_l0;
+    /* current batch */
+    size_t batch;
+    uint64_t *sigma;
+    uint8_t *bad;
+    uint32_t *hx, *hz;   /* last downloaded plain x, z: [nl][batch] */
+    int have_plain;
+    uint64_t B1;
+    /* tape cache */
+    gecm_tape_t tape;
+    uint64_t tape_B1;
+    int tape_on_dev;
+    double last_ms;
+};
+
+static int pick_nl(int nbits)
+{
+    int need = (nbits + 5 + LIMB_BITS - 1) / LIMB_BITS;   /* R = 2^(28 nl) >= 32 N */
+    for (const int *p = gecm_dev_supported_nl(); *p; p++)
+        if (*p >= need) return *p;
+    return 0;
+}
+
+static void pow2_mod(mpl_t *r, unsigned e, const mpl_t *m)
+{
+    mpl_t t;
+    mpl_set_u64(&t, 1);
+    mpl_shl(&t, &t, e);
+    mpl_mod(r, &t, m);
+}
+
+int gecm_create(gecm_ctx **out, int device, const char *n_str, int digitbits)
+{
+    if (!out || !n_str || (digitbits != 52 && digitbits != 32)) {
+        set_err("gecm_create: bad argument (digitbits must be 52 or 32)");
+        return GECM_ERR_ARG;
+    }
+    gecm_ctx *c = (gecm_ctx *)calloc(1, sizeof *c);
+    if (!c) return GECM_ERR_NOMEM;
+    if (mpl_set_str(&c->N, n_str) || !mpl_is_odd(&c->N) || mpl_cmp_u64(&c->N, 3) < 0) {
+        set_err("gecm_create: N must be an odd integer >= 3 (decimal or 0x-hex)");
+        free(c);
+        return GECM_ERR_ARG;
+    }
+    c->device = device;
+    c->digitbits = digitbits;
+    c->nbits = mpl_bits(&c->N);
+    /* main.c:465-483: MAXBITS = smallest multiple of 208 (128) strictly greater than bitlen */
+    int step = digitbits == 52 ? 208 : 128;
+    c->maxbits = step;
+    while (c->maxbits <= c->nbits) c->maxbits += step;
+    c->nwords = c->maxbits / digitbits;
+    c->nl = pick_nl(c->nbits);
+    if (!c->nl || c->maxbits + 64 > MPL_MAXL * 16) {
+        set_err("gecm_create: N of %d bits is larger than this build supports", c->nbits);
+        free(c);
+        return GECM_ERR_ARG;
+    }
+    int nl = c->nl;
+    unsigned rint_bits = (unsigned)(LIMB_BITS * nl), rref_bits = (unsigned)c->maxbits;
+    mpl_t t, inv;
+    pow2_mod(&c->rref_mod_n, rref_bits, &c->N);
+    pow2_mod(&c->rint_mod_n, rint_bits, &c->N);
+    mpl_invmod(&inv, &c->rref_mod_n, &c->N);
+    mpl_mulmod(&c->ref_to_int, &c->rint_mod_n, &inv, &c->N);
+    mpl_invmod(&inv, &c->rint_mod_n, &c->N);
+    mpl_mulmod(&c->int_to_ref, &c->rref_mod_n, &inv, &c->N);
+    /* rho = -N^-1 mod 2^digitbits (main.c:627-628, 636-640) and mod 2^28 */
+    mpl_t two64;
+    mpl_set_u64(&two64, 1);
+    mpl_shl(&two64, &two64, 64);
+    mpl_invmod(&inv, &c->N, &two64);
+    mpl_sub(&t, &two64, &inv);
+    uint64_t nhat = mpl_get_u64(&t);
+    c->rho_ref = digitbits == 52 ? (nhat & 0xfffffffffffffull) : (nhat & 0xffffffffull);
+    c->rho28 = (uint32_t)(nhat & ((1u << LIMB_BITS) - 1));
+    c->n28 = (uint32_t *)calloc((size_t)nl * 4, sizeof(uint32_t));
+    if (!c->n28) { free(c); return GECM_ERR_NOMEM; }
+    c->kp28 = c->n28 + nl;
+    c->one28 = c->kp28 + nl;
+    c->fix28 = c->one28 + nl;
+    mpl_to_limbs32(c->n28, 1, nl, LIMB_BITS, &c->N);
+    mpl_to_limbs32(c->one28, 1, nl, LIMB_BITS, &c->rint_mod_n);
+    /* K = 2^k N in [R/32, R/16): bits(K) = 28 nl - 4 */
+    mpl_t K;
+    mpl_shl(&K, &c->N, (unsigned)(LIMB_BITS * nl - 4 - c->nbits));
+    uint32_t *kl = (uint32_t *)calloc((size_t)nl, sizeof(uint32_t));
+    if (!kl) { free(c->n28); free(c); return GECM_ERR_NOMEM; }
+    mpl_to_limbs32(kl, 1, nl, LIMB_BITS, &K);
+    /* K' : same value, limbs shifted into [2^28-1, 2^29): +2^28 at limb 0, +2^28-1 in the middle,
+     * -1 at the top (see csrc/gecm_field.hpp) */
+    for (int i = 0; i < nl; i++) {
+        if (i == 0) c->kp28[i] = kl[i] + (1u << LIMB_BITS);
+        else if (i < nl - 1) c->kp28[i] = kl[i] + (1u << LIMB_BITS) - 1;
+        else c->kp28[i] = kl[i] - 1;
+    }
+    free(kl);
+    /* fix = Rint^2 / Rref mod N = Rint * ref_to_int */
+    mpl_mulmod(&t, &c->rint_mod_n, &c->ref_to_int, &c->N);
+    mpl_to_limbs32(c->fix28, 1, nl, LIMB_BITS, &t);
+    if (gecm_dev_open(&c->dev, device, nl, c->n28, c->kp28, c->one28, c->rho28)) {
+        set_err("gecm_create: %s", gecm_dev_error());
+        free(c->n28);
+        free(c);
+        return GECM_ERR_DEVICE;
+    }
+    *out = c;
+    return GECM_OK;
+}
+
+static void free_batch(gecm_ctx *c)
+{
+    free(c->sigma); free(c->bad); free(c->hx); free(c->hz);
+    c->sigma = NULL; c->bad = NULL; c->hx = c->hz = NULL;
+    c->batch = 0;
+    c->have_plain = 0;
+}
+
+void gecm_destroy(gecm_ctx *c)
+{
+    if (!c) return;
+    gecm_dev_close(c->dev);
+    gecm_dev_close(c->dev_l0);
+    gecm_tape_free(&c->tape);
+    free_batch(c);
+    free(c->n28);
+    free(c);
+}
+
+int gecm_get_config(const gecm_ctx *c, gecm_config *cfg)
+{
+    if (!c || !cfg) return GECM_ERR_ARG;
+    cfg->digitbits = c->digitbits;
+    cfg->nwords = c->nwords;
+    cfg->maxbits = c->maxbits;
+    cfg->nbits = c->nbits;
+    cfg->dev_limbs = c->nl;
+    cfg->device = c->device;
+    cfg->rho = c->rho_ref;
+    return GECM_OK;
+}
+
+int gecm_device_name(gecm_ctx *c, char *buf, size_t len)
+{
+    if (gecm_dev_device_name(c->dev, buf, len)) { set_err("%s", gecm_dev_error()); return GECM_ERR_DEVICE; }
+    return GECM_OK;
+}
+
+/* ---- reference vec layout <-> mpl ---------------------------------------------------------- */
+static void vec_get(const gecm_ctx *c, mpl_t *r, const void *vec, size_t batch, size_t lane)
+{
+    if (c->digitbits == 52) mpl_from_limbs64(r, (const uint64_t *)vec + lane, batch, c->nwords, 52);
+    else mpl_from_limbs32(r, (const uint32_t *)vec + lane, batch, c->nwords, 32);
+}
+
+static void vec_put(const gecm_ctx *c, void *vec, size_t batch, size_t lane, const mpl_t *v)
+{
+    if (c->digitbits == 52) mpl_to_limbs64((uint64_t *)vec + lane, batch, c->nwords, 52, v);
+    else mpl_to_limbs32((uint32_t *)vec + lane, batch, c->nwords, 32, v);
+}
+
+int gecm_get_one(const gecm_ctx *c, void *one_limbs)
+{
+    if (!c || !one_limbs) return GECM_ERR_ARG;
+    vec_put(c, one_limbs, 1, 0, &c->rref_mod_n);
+    return GECM_OK;
+}
+
+/* ---- L0 ------------------------------------------------------------------------------------ */
+static int l0_call(gecm_ctx *c, int op, const void *a, const void *b, void *r0, void *r1, size_t batch)
+{
+    if (!c || !a || !r0 || batch == 0) { set_err("L0: bad argument"); return GECM_ERR_ARG; }
+    if (!c->dev_l0 &&
+        gecm_dev_open(&c->dev_l0, c->device, c->nl, c->n28, c->kp28, c->one28, c->rho28)) {
+        set_err("L0: %s", gecm_dev_error());
+        return GECM_ERR_DEVICE;
+    }
+    int nl = c->nl;
+    size_t words = (size_t)nl * batch;
+    uint32_t *ha = (uint32_t *)malloc(words * 4 * 4);
+    if (!ha) return GECM_ERR_NOMEM;
+    uint32_t *hb = ha + words, *hc = hb + words, *hd = hc + words;
+    mpl_t v;
+    for (size_t i = 0; i < batch; i++) {
+        vec_get(c, &v, a, batch, i);
+        if (mpl_cmp(&v, &c->N) >= 0) { free(ha); set_err("L0: operand a[%zu] not < N", i); return GECM_ERR_ARG; }
+        mpl_to_limbs32(ha + i, batch, nl, LIMB_BITS, &v);
+        if (b) {
+            vec_get(c, &v, b, batch, i);
+            if (mpl_cmp(&v, &c->N) >= 0) { free(ha); set_err("L0: operand b[%zu] not < N", i); return GECM_ERR_ARG; }
+        }
+        mpl_to_limbs32(hb + i, batch, nl, LIMB_BITS, &v);
+    }
+    int rc = gecm_dev_l0(c->dev_l0, op, ha, hb, hc, hd, batch, c->fix28);
+    if (rc) { free(ha); set_err("L0: %s", gecm_dev_error()); return GECM_ERR_DEVICE; }
+    for (size_t i = 0; i < batch; i++) {
+        mpl_from_limbs32(&v, hc + i, batch, nl, LIMB_BITS);
+        vec_put(c, r0, batch, i, &v);
+        if (op == GECM_L0_ADDSUB) {
+            mpl_from_limbs32(&v, hd + i, batch, nl, LIMB_BITS);
+            vec_put(c, r1, batch, i, &v);
+        }
+    }
+    free(ha);
+    return GECM_OK;
+}
+
+int gecm_vecmulmod(gecm_ctx *c, const void *a, const void *b, void *r, size_t batch)
+{
+    return b ? l0_call(c, GECM_L0_MUL, a, b, r, NULL, batch) : GECM_ERR_ARG;
+}
+int gecm_vecsqrmod(gecm_ctx *c, const void *a, void *r, size_t batch)
+{
+    return l0_call(c, GECM_L0_SQR, a, NULL, r, NULL, batch);
+}
+int gecm_vecaddmod(gecm_ctx *c, const void *a, const void *b, void *r, size_t batch)
+{
+    return b ? l0_call(c, GECM_L0_ADD, a, b, r, NULL, batch) : GECM_ERR_ARG;
+}
+int gecm_vecsubmod(gecm_ctx *c, const void *a, const void *b, void *r, size_t batch)
+{
+    return b ? l0_call(c, GECM_L0_SUB, a, b, r, NULL, batch) : GECM_ERR_ARG;
+}
+int gecm_vecaddsubmod(gecm_ctx *c, const void *a, const void *b, void *sum, void *diff, size_t batch)
+{
+    return (b && diff) ? l0_call(c, GECM_L0_ADDSUB, a, b, sum, diff, batch) : GECM_ERR_ARG;
+}
+
+/* ---- phase 0 -------------------------------------------------------------------------------- */
+static int alloc_batch(gecm_ctx *c, size_t batch)
+{
+    free_batch(c);
+    c->sigma = (uint64_t *)calloc(batch, sizeof(uint64_t));
+    c->bad = (uint8_t *)calloc(batch, 1);
+    c->hx = (uint32_t *)calloc(batch * (size_t)c->nl, 4);
+    c->hz = (uint32_t *)calloc(batch * (size_t)c->nl, 4);
+    if (!c->sigma || !c->bad || !c->hx || !c->hz) { free_batch(c); return GECM_ERR_NOMEM; }
+    c->batch = batch;
+    if (gecm_dev_resize(c->dev, batch)) { set_err("%s", gecm_dev_error()); return GECM_ERR_DEVICE; }
+    return GECM_OK;
+}
+
+/* Suyama curve for one sigma up to (but not including) the two modular inversions
+ * (ecm.c:1587-1641, 1717-1722): outputs x3 = u^3 mod n, z3 = v^3 mod n, num = (v-u)^3 (3u+v) mod n,
+ * den = 16 u^3 v mod n. */
+static void suyama_pre(const mpl_t *n, uint64_t sigma, mpl_t *x3, mpl_t *z3, mpl_t *num, mpl_t *den)
+{
+    mpl_t u, v, t1, t2, t3, t4;
+    mpl_set_u64(&v, sigma);
+    mpl_shl(&v, &v, 2);                 /* v = 4 sigma            ecm.c:1588-1589 */
+    mpl_set_u64(&u, sigma);
+    mpl_mul(&u, &u, &u);
+    mpl_set_u64(&t1, 5);
+    mpl_sub(&u, &u, &t1);               /* u = sigma^2 - 5        ecm.c:1596-1598 */
+    mpl_mul(&t1, &u, &u);
+    mpl_mul(&t1, &t1, &u);
+    mpl_mod(x3, &t1, n);                /* x = u^3                ecm.c:1601-1603 */
+    mpl_mul(&t1, &v, &v);
+    mpl_mul(&t1, &t1, &v);
+    mpl_mod(z3, &t1, n);                /* z = v^3                ecm.c:1607-1609 */
+    /* (v - u) mod n                                               ecm.c:1615-1623 */
+    mpl_t um, vm;
+    mpl_mod(&um, &u, n);
+    mpl_mod(&vm, &v, n);
+    mpl_submod(&t1, &vm, &um, n);
+    mpl_mulmod(&t2, &t1, &t1, n);
+    mpl_mulmod(&t4, &t2, &t1, n);       /* (v-u)^3                ecm.c:1626-1629 */
+    mpl_mul_u64(&t3, &u, 3);
+    mpl_add(&t3, &t3, &v);
+    mpl_mod(&t3, &t3, n);               /* 3u + v                 ecm.c:1632-1634 */
+    mpl_mulmod(num, &t3, &t4, n);       /* a = (v-u)^3 (3u+v)     ecm.c:1637-1638 */
+    mpl_mul_u64(&t2, x3, 16);
+    mpl_mul(&t2, &t2, &v);
+    mpl_mod(den, &t2, n);               /* 16 u^3 v               ecm.c:1718-1720 */
+}
+
+int gecm_build_curves(gecm_ctx *c, const uint64_t *sigma, size_t batch)
+{
+    if (!c || !sigma || batch == 0) { set_err("gecm_build_curves: bad argument"); return GECM_ERR_ARG; }
+    int rc = alloc_batch(c, batch);
+    if (rc) return rc;
+    for (size_t i = 0; i < batch; i++) {
+        if (sigma[i] < 6) { set_err("gecm_build_curves: sigma[%zu] < 6", i); return GECM_ERR_ARG; }
+        c->sigma[i] = sigma[i];
+    }
+    int nl = c->nl, anybad = 0;
+    size_t words = (size_t)nl * batch;
+    uint32_t *hX = (uint32_t *)calloc(words * 3, 4);
+    mpl_t *x3 = (mpl_t *)malloc(batch * sizeof(mpl_t) * 2);
+    mpl_t *dens = (mpl_t *)malloc(batch * 2 * sizeof(mpl_t));
+    mpl_t *pref = (mpl_t *)malloc(batch * 2 * sizeof(mpl_t));
+    if (!hX || !x3 || !dens || !pref) { free(hX); free(x3); free(dens); free(pref); return GECM_ERR_NOMEM; }
+    uint32_t *hZ = hX + words, *hS = hZ + words;
+    mpl_t *num = x3 + batch;
+    /* the two inversions per curve, mpz_invert(16u^3v) ecm.c:1745 and mpz_invert(v^3) ecm.c:1759,
+     * share the modulus across the whole batch: Montgomery's simultaneous inversion, one
+     * extended Euclid per batch instead of two per curve.  Inverses mod N are unique, so the
+     * values are the ones GMP returns. */
+    for (size_t i = 0; i < batch; i++)
+        suyama_pre(&c->N, sigma[i], &x3[i], &dens[2 * i + 1], &num[i], &dens[2 * i]);
+    size_t m = 2 * batch;
+    int batch_ok = 1;
+    pref[0] = dens[0];
+    for (size_t i = 1; i < m; i++) mpl_mulmod(&pref[i], &pref[i - 1], &dens[i], &c->N);
+    mpl_t inv, t;
+    if (!mpl_invmod(&inv, &pref[m - 1], &c->N)) batch_ok = 0;
+    mpl_t *invs = pref;   /* overwritten back to front */
+    if (batch_ok) {
+        for (size_t i = m - 1; i > 0; i--) {
+            mpl_mulmod(&t, &inv, &pref[i - 1], &c->N);      /* dens[i]^-1 */
+            mpl_mulmod(&inv, &inv, &dens[i], &c->N);
+            invs[i] = t;
+        }
+        invs[0] = inv;
+    } else {
+        for (size_t i = 0; i < m; i++)
+            if (!mpl_invmod(&invs[i], &dens[i], &c->N)) { c->bad[i / 2] = 1; anybad = 1; invs[i].n = 0; }
+    }
+    for (size_t i = 0; i < batch; i++) {
+        mpl_t A, X, Xm, Sm;
+        if (c->bad[i]) continue;   /* lanes stay zero */
+        mpl_mulmod(&A, &num[i], &invs[2 * i], &c->N);          /* b = a / 16u^3v   ecm.c:1752-1753 */
+        mpl_mulmod(&X, &x3[i], &invs[2 * i + 1], &c->N);       /* X = u^3 / v^3, Z = 1  ecm.c:1759-1761 */
+        /* into Montgomery form (ecm.c:1763-1772), internal radix */
+        mpl_mulmod(&Xm, &X, &c->rint_mod_n, &c->N);
+        mpl_mulmod(&Sm, &A, &c->rint_mod_n, &c->N);
+        mpl_to_limbs32(hX + i, batch, nl, LIMB_BITS, &Xm);
+        mpl_to_limbs32(hZ + i, batch, nl, LIMB_BITS, &c->rint_mod_n);
+        mpl_to_limbs32(hS + i, batch, nl, LIMB_BITS, &Sm);
+    }
+    rc = gecm_dev_upload(c->dev, hX, hZ, hS);
+    free(hX); free(x3); free(dens); free(pref);
+    if (rc) { set_err("%s", gecm_dev_error()); return GECM_ERR_DEVICE; }
+    return anybad ? 1 : GECM_OK;
+}
+
+int gecm_upload_points(gecm_ctx *c, const void *X, const void *Z, const void *s, size_t batch)
+{
+    if (!c || !X || !Z || !s || batch == 0) { set_err("gecm_upload_points: bad argument"); return GECM_ERR_ARG; }
+    int rc = alloc_batch(c, batch);
+    if (rc) return rc;
+    int nl = c->nl;
+    size_t words = (size_t)nl * batch;
+    uint32_t *h = (uint32_t *)calloc(words * 3, 4);
+    if (!h) return GECM_ERR_NOMEM;
+    const void *src[3] = {X, Z, s};
+    for (int k = 0; k < 3; k++)
+        for (size_t i = 0; i < batch; i++) {
+            mpl_t v;
+            vec_get(c, &v, src[k], batch, i);
+            if (mpl_cmp(&v, &c->N) >= 0) { free(h); set_err("gecm_upload_points: operand not < N"); return GECM_ERR_ARG; }
+            mpl_mulmod(&v, &v, &c->ref_to_int, &c->N);
+            mpl_to_limbs32(h + (size_t)k * words + i, batch, nl, LIMB_BITS, &v);
+        }
+    rc = gecm_dev_upload(c->dev, h, h + words, h + 2 * words);
+    free(h);
+    if (rc) { set_err("%s", gecm_dev_error()); return GECM_ERR_DEVICE; }
+    return GECM_OK;
+}
+
+/* ---- phase 1 -------------------------------------------------------------------------------- */
+int gecm_stage1(gecm_ctx *c, uint64_t B1)
+{
+    if (!c || c->batch == 0) { set_err("gecm_stage1: no curves uploaded"); return GECM_ERR_STATE; }
+    if (B1 < 2 || B1 > 100000000ull) { set_err("gecm_stage1: B1 must be in [2, 1e8]"); return GECM_ERR_ARG; }
+    if (c->tape_B1 != B1 || !c->tape.ops) {
+        gecm_tape_free(&c->tape);
+        int rc = gecm_tape_build_stage1(&c->tape, B1);
+        if (rc) { set_err("gecm_stage1: tape build failed (%d)", rc); return rc == -1 ? GECM_ERR_NOMEM : GECM_ERR_STATE; }
+        c->tape_B1 = B1;
+        c->tape_on_dev = 0;
+    }
+    if (!c->tape_on_dev) {
+        if (gecm_dev_set_tape(c->dev, c->tape.ops, c->tape.len)) { set_err("%s", gecm_dev_error()); return GECM_ERR_DEVICE; }
+        c->tape_on_dev = 1;
+    }
+    c->B1 = B1;
+    c->have_plain = 0;
+    if (gecm_dev_stage1(c->dev)) { set_err("%s", gecm_dev_error()); return GECM_ERR_DEVICE; }
+    return GECM_OK;
+}
+
+int gecm_sync(gecm_ctx *c)
+{
+    if (!c) return GECM_ERR_ARG;
+    if (gecm_dev_sync(c->dev)) { set_err("%s", gecm_dev_error()); return GECM_ERR_DEVICE; }
+    c->last_ms = gecm_dev_last_kernel_ms(c->dev);
+    return GECM_OK;
+}
+
+double gecm_last_kernel_ms(const gecm_ctx *c) { return c ? c->last_ms : 0.0; }
+
+int gecm_get_stage1_stats(const gecm_ctx *c, gecm_stage1_stats *st)
+{
+    if (!c || !st || !c->tape.ops) return GECM_ERR_STATE;
+    st->ptadds = c->tape.ptadds;
+    st->ptdups = c->tape.ptdups;
+    st->last_prime = c->tape.last_prime;
+    st->tape_len = c->tape.len;
+    return GECM_OK;
+}
+
+int gecm_download_points(gecm_ctx *c, void *X, void *Z)
+{
+    if (!c || !X || !Z || c->batch == 0) return GECM_ERR_ARG;
+    size_t batch = c->batch, words = (size_t)c->nl * batch;
+    uint32_t *h = (uint32_t *)malloc(words * 2 * 4);
+    if (!h) return GECM_ERR_NOMEM;
+    if (gecm_dev_download_mont(c->dev, h, h + words)) { free(h); set_err("%s", gecm_dev_error()); return GECM_ERR_DEVICE; }
+    void *dst[2] = {X, Z};
+    for (int k = 0; k < 2; k++)
+        for (size_t i = 0; i < batch; i++) {
+            mpl_t v;
+            mpl_from_limbs32(&v, h + (size_t)k * words + i, batch, c->nl, LIMB_BITS);
+            mpl_mulmod(&v, &v, &c->int_to_ref, &c->N);
+            vec_put(c, dst[k], batch, i, &v);
+        }
+    free(h);
+    return GECM_OK;
+}
+
+static int fetch_plain(gecm_ctx *c)
+{
+    if (c->have_plain) return GECM_OK;
+    if (c->batch == 0) { set_err("no batch"); return GECM_ERR_STATE; }
+    if (gecm_dev_download_plain(c->dev, c->hx, c->hz)) { set_err("%s", gecm_dev_error()); return GECM_ERR_DEVICE; }
+    c->have_plain = 1;
+    return GECM_OK;
+}
+
+int gecm_download_points_plain(gecm_ctx *c, void *x, void *z)
+{
+    if (!c || !x || !z) return GECM_ERR_ARG;
+    int rc = fetch_plain(c);
+    if (rc) return rc;
+    for (size_t i = 0; i < c->batch; i++) {
+        mpl_t v;
+        mpl_from_limbs32(&v, c->hx + i, c->batch, c->nl, LIMB_BITS);
+        vec_put(c, x, c->batch, i, &v);
+        mpl_from_limbs32(&v, c->hz + i, c->batch, c->nl, LIMB_BITS);
+        vec_put(c, z, c->batch, i, &v);
+    }
+    return GECM_OK;
+}
+
+int gecm_format_save_line(gecm_ctx *c, size_t k, char *buf, size_t buflen)
+{
+    if (!c || !buf || k >= c->batch) return GECM_ERR_ARG;
+    int rc = fetch_plain(c);
+    if (rc) return rc;
+    static __thread char hn[MPL_MAXL * 10 + 2], hxs[MPL_MAXL * 10 + 2], hzs[MPL_MAXL * 10 + 2];
+    mpl_t v;
+    mpl_get_hex(hn, &c->N);
+    mpl_from_limbs32(&v, c->hx + k, c->batch, c->nl, LIMB_BITS);
+    mpl_get_hex(hxs, &v);
+    mpl_from_limbs32(&v, c->hz + k, c->batch, c->nl, LIMB_BITS);
+    mpl_get_hex(hzs, &v);
+    /* ecm.c:1372-1380 */
+    int n = snprintf(buf, buflen, "METHOD=ECM; SIGMA=%llu; B1=%llu; N=0x%s; X=0x%s; Z=0x%s; PROGRAM=AVX-ECM;\n",
+                     (unsigned long long)c->sigma[k], (unsigned long long)c->B1, hn, hxs, hzs);
+    if (n < 0 || (size_t)n >= buflen) { set_err("gecm_format_save_line: buffer too small"); return GECM_ERR_ARG; }
+    return n;
+}
+
+int gecm_stage1_factor(gecm_ctx *c, size_t k, char *dec, size_t declen, int *is_prp)
+{
+    if (!c || k >= c->batch) return GECM_ERR_ARG;
+    int rc = fetch_plain(c);
+    if (rc) return rc;
+    mpl_t z, g;
+    mpl_from_limbs32(&z, c->hz + k, c->batch, c->nl, LIMB_BITS);
+    /* check_factor, ecm.c:2542-2557: gcd(Z, N); the reference passes Z in Montgomery form, and
+     * gcd(z R mod N, N) = gcd(z, N) because R is a power of two and N is odd. */
+    mpl_gcd(&g, &z, &c->N);
+    if (mpl_cmp_u64(&g, 1) > 0 && mpl_cmp(&g, &c->N) != 0) {
+        static __thread char tmp[MPL_MAXL * 10 + 16];
+        int n = mpl_get_dec(tmp, &g);
+        if (dec && declen) {
+            if ((size_t)n >= declen) { set_err("gecm_stage1_factor: buffer too small"); return GECM_ERR_ARG; }
+            memcpy(dec, tmp, (size_t)n + 1);
+        }
+        if (is_prp) *is_prp = mpl_probab_prime(&g, 3);   /* ecm.c:1346 */
+        return 1;
+    }
+    return 0;
+}

@@ -1,0 +1,209 @@
+"""pyecm — thin ctypes binding of libgecm's C ABI (include/gecm.h) for tests and bench.py.
+
+Plumbing only: every call goes straight to the shared library; there is no Python fallback.
+If libgecm.so is missing or fails to load, importing this module raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libgecm.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError("libgecm.so not built: run `make -C avx-ecm_amd -j8` (or __graft_entry__.build())")
+lib = ctypes.CDLL(LIB_PATH)
+
+c_void_p, c_int, c_size_t, c_char_p, c_u64, c_double = (ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t,
+                                                         ctypes.c_char_p, ctypes.c_uint64, ctypes.c_double)
+
+
+class Config(ctypes.Structure):
+    _fields_ = [("digitbits", c_int), ("nwords", c_int), ("maxbits", c_int), ("nbits", c_int),
+                ("dev_limbs", c_int), ("device", c_int), ("rho", c_u64)]
+
+
+class Stage1Stats(ctypes.Structure):
+    _fields_ = [("ptadds", c_u64), ("ptdups", c_u64), ("last_prime", c_u64), ("tape_len", c_u64)]
+
+
+def _sig(name, res, *args):
+    f = getattr(lib, name)
+    f.restype = res
+    f.argtypes = list(args)
+    return f
+
+
+# every symbol include/gecm.h declares
+EXPORTS = ["gecm_last_error", "gecm_device_count", "gecm_version", "gecm_create", "gecm_destroy",
+           "gecm_get_config", "gecm_device_name", "gecm_get_one", "gecm_vecmulmod", "gecm_vecsqrmod",
+           "gecm_vecaddmod", "gecm_vecsubmod", "gecm_vecaddsubmod", "gecm_build_curves",
+           "gecm_upload_points", "gecm_stage1", "gecm_sync", "gecm_last_kernel_ms",
+           "gecm_get_stage1_stats", "gecm_download_points", "gecm_download_points_plain",
+           "gecm_format_save_line", "gecm_stage1_factor"]
+
+_sig("gecm_last_error", c_char_p)
+_sig("gecm_device_count", c_int)
+_sig("gecm_version", c_char_p)
+_sig("gecm_create", c_int, ctypes.POINTER(c_void_p), c_int, c_char_p, c_int)
+_sig("gecm_destroy", None, c_void_p)
+_sig("gecm_get_config", c_int, c_void_p, ctypes.POINTER(Config))
+_sig("gecm_device_name", c_int, c_void_p, c_char_p, c_size_t)
+_sig("gecm_get_one", c_int, c_void_p, c_void_p)
+_sig("gecm_vecmulmod", c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t)
+_sig("gecm_vecsqrmod", c_int, c_void_p, c_void_p, c_void_p, c_size_t)
+_sig("gecm_vecaddmod", c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t)
+_sig("gecm_vecsubmod", c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t)
+_sig("gecm_vecaddsubmod", c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t)
+_sig("gecm_build_curves", c_int, c_void_p, ctypes.POINTER(c_u64), c_size_t)
+_sig("gecm_upload_points", c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t)
+_sig("gecm_stage1", c_int, c_void_p, c_u64)
+_sig("gecm_sync", c_int, c_void_p)
+_sig("gecm_last_kernel_ms", c_double, c_void_p)
+_sig("gecm_get_stage1_stats", c_int, c_void_p, ctypes.POINTER(Stage1Stats))
+_sig("gecm_download_points", c_int, c_void_p, c_void_p, c_void_p)
+_sig("gecm_download_points_plain", c_int, c_void_p, c_void_p, c_void_p)
+_sig("gecm_format_save_line", c_int, c_void_p, c_size_t, c_char_p, c_size_t)
+_sig("gecm_stage1_factor", c_int, c_void_p, c_size_t, c_char_p, c_size_t, ctypes.POINTER(c_int))
+
+
+class GecmError(RuntimeError):
+    pass
+
+
+def _chk(rc, what):
+    if rc < 0:
+        raise GecmError("%s failed (%d): %s" % (what, rc, lib.gecm_last_error().decode()))
+    return rc
+
+
+def device_count():
+    return lib.gecm_device_count()
+
+
+class Engine:
+    """One gecm_ctx: N + limb format + device."""
+
+    def __init__(self, n, digitbits=52, device=0):
+        self._h = c_void_p()
+        _chk(lib.gecm_create(ctypes.byref(self._h), device, str(n).encode(), digitbits), "gecm_create")
+        self.cfg = Config()
+        _chk(lib.gecm_get_config(self._h, ctypes.byref(self.cfg)), "gecm_get_config")
+        self.n = int(str(n), 0) if isinstance(n, str) else int(n)
+        self.batch = 0
+
+    def close(self):
+        if self._h:
+            lib.gecm_destroy(self._h)
+            self._h = c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- reference vec layout helpers: data[lane + limb*batch] ----
+    def _ctype(self):
+        return ctypes.c_uint64 if self.cfg.digitbits == 52 else ctypes.c_uint32
+
+    def pack(self, values):
+        b, nw, db = len(values), self.cfg.nwords, self.cfg.digitbits
+        arr = (self._ctype() * (b * nw))()
+        mask = (1 << db) - 1
+        for lane, v in enumerate(values):
+            for j in range(nw):
+                arr[lane + j * b] = (v >> (db * j)) & mask
+        return arr
+
+    def unpack(self, arr, b):
+        nw, db = self.cfg.nwords, self.cfg.digitbits
+        return [sum(int(arr[lane + j * b]) << (db * j) for j in range(nw)) for lane in range(b)]
+
+    def empty(self, b):
+        return (self._ctype() * (b * self.cfg.nwords))()
+
+    # ---- L0 ----
+    def vecmulmod(self, a, b):
+        n = len(a)
+        out = self.empty(n)
+        _chk(lib.gecm_vecmulmod(self._h, self.pack(a), self.pack(b), out, n), "gecm_vecmulmod")
+        return self.unpack(out, n)
+
+    def vecsqrmod(self, a):
+        n = len(a)
+        out = self.empty(n)
+        _chk(lib.gecm_vecsqrmod(self._h, self.pack(a), out, n), "gecm_vecsqrmod")
+        return self.unpack(out, n)
+
+    def vecaddmod(self, a, b):
+        n = len(a)
+        out = self.empty(n)
+        _chk(lib.gecm_vecaddmod(self._h, self.pack(a), self.pack(b), out, n), "gecm_vecaddmod")
+        return self.unpack(out, n)
+
+    def vecsubmod(self, a, b):
+        n = len(a)
+        out = self.empty(n)
+        _chk(lib.gecm_vecsubmod(self._h, self.pack(a), self.pack(b), out, n), "gecm_vecsubmod")
+        return self.unpack(out, n)
+
+    def vecaddsubmod(self, a, b):
+        n = len(a)
+        s, d = self.empty(n), self.empty(n)
+        _chk(lib.gecm_vecaddsubmod(self._h, self.pack(a), self.pack(b), s, d, n), "gecm_vecaddsubmod")
+        return self.unpack(s, n), self.unpack(d, n)
+
+    # ---- L1 ----
+    def build_curves(self, sigmas):
+        arr = (c_u64 * len(sigmas))(*sigmas)
+        self.batch = len(sigmas)
+        return _chk(lib.gecm_build_curves(self._h, arr, len(sigmas)), "gecm_build_curves")
+
+    def upload_points(self, X, Z, s):
+        self.batch = len(X)
+        _chk(lib.gecm_upload_points(self._h, self.pack(X), self.pack(Z), self.pack(s), len(X)), "gecm_upload_points")
+
+    def stage1(self, b1, sync=True):
+        _chk(lib.gecm_stage1(self._h, b1), "gecm_stage1")
+        if sync:
+            self.sync()
+
+    def sync(self):
+        _chk(lib.gecm_sync(self._h), "gecm_sync")
+
+    def last_kernel_ms(self):
+        return lib.gecm_last_kernel_ms(self._h)
+
+    def stage1_stats(self):
+        st = Stage1Stats()
+        _chk(lib.gecm_get_stage1_stats(self._h, ctypes.byref(st)), "gecm_get_stage1_stats")
+        return st
+
+    def download_points(self):
+        X, Z = self.empty(self.batch), self.empty(self.batch)
+        _chk(lib.gecm_download_points(self._h, X, Z), "gecm_download_points")
+        return self.unpack(X, self.batch), self.unpack(Z, self.batch)
+
+    def download_points_plain(self):
+        X, Z = self.empty(self.batch), self.empty(self.batch)
+        _chk(lib.gecm_download_points_plain(self._h, X, Z), "gecm_download_points_plain")
+        return self.unpack(X, self.batch), self.unpack(Z, self.batch)
+
+    def save_line(self, k):
+        buf = ctypes.create_string_buffer(8192)
+        _chk(lib.gecm_format_save_line(self._h, k, buf, len(buf)), "gecm_format_save_line")
+        return buf.value.decode()
+
+    def save_lines(self):
+        return [self.save_line(k) for k in range(self.batch)]
+
+    def stage1_factor(self, k):
+        buf = ctypes.create_string_buffer(2048)
+        prp = c_int(0)
+        rc = _chk(lib.gecm_stage1_factor(self._h, k, buf, len(buf), ctypes.byref(prp)), "gecm_stage1_factor")
+        return (int(buf.value.decode()), bool(prp.value)) if rc == 1 else None
+
+    def device_name(self):
+        buf = ctypes.create_string_buffer(256)
+        _chk(lib.gecm_device_name(self._h, buf, len(buf)), "gecm_device_name")
+        return buf.value.decode()

@@ -1,0 +1,122 @@
+/* gecm.h — public C ABI of libgecm, the MI355X-native engine for the hot path of bbuhrow/avx-ecm.
+ *
+ * Drop-in boundary.  The reference reaches its hot path through
+ *   (L0) five global function pointers bound in main.c:642-702 and declared in avx_ecm.h:205-209:
+ *          vecmulmod_ptr / vecsqrmod_ptr / vecaddmod_ptr / vecsubmod_ptr / vecaddsubmod_ptr
+ *   (L1) four per-thread phase functions dispatched by vececm through tpool_go
+ *        (ecm.c:1195, 1234, 1407, 1460):
+ *          ecm_build_curve_work_fcn  ecm.c:201-246   -> build_one_curve ecm.c:1548-1803
+ *          ecm_stage1_work_fcn       ecm.c:167-176   -> ecm_stage1      ecm.c:1806-1854
+ *          ecm_stage2_init_work_fcn  ecm.c:178-186   -> ecm_stage2_init ecm.c:2201-2340
+ *          ecm_stage2_work_fcn       ecm.c:188-199   -> ecm_stage2_pair ecm.c:2342-2540
+ * This header exports exactly those seams, on a batch of B curves instead of VECLEN=8/16 lanes.
+ * Every entry point is extern "C", takes plain pointers and sizes, returns an int status
+ * (0 = ok, < 0 = error; text from gecm_last_error()), and never exits the process (the reference
+ * printf+exit()s: util.c:56-59, ecm.c:969-970).
+ *
+ * Vector operands ("vec") use the REFERENCE's memory layout (avx_ecm.h:111-116, main.c:117-138):
+ *   data[lane + limb * batch], limb-major / curve-minor, limbs of DIGITBITS bits held in
+ *   uint64_t (DIGITBITS = 52) or uint32_t (DIGITBITS = 32), NWORDS limbs per value, values in the
+ *   reference's Montgomery form x * 2^(DIGITBITS*NWORDS) mod N, canonical in [0, N).
+ * So a maintainer can pass bignum->data straight through (with batch = VECLEN) — INTEGRATION.md.
+ *
+ * Ownership: the context owns all device memory; every host array is caller-owned and copied.
+ * Threading: one context per GPU, used by one host thread at a time; contexts are independent.
+ */
+#ifndef GECM_H
+#define GECM_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gecm_ctx gecm_ctx;
+
+#define GECM_OK 0
+#define GECM_ERR_ARG (-2)
+#define GECM_ERR_DEVICE (-1)
+#define GECM_ERR_NOMEM (-3)
+#define GECM_ERR_STATE (-4)
+
+const char *gecm_last_error(void);
+int gecm_device_count(void);
+const char *gecm_version(void);
+
+/* ---- configuration (replaces monty_alloc + main.c:465-483, 597-640) ------------------------
+ * n_str: the number to factor, decimal or 0x-hex (odd, > 1).
+ * digitbits: 52 or 32 — the reference limb format used at THIS boundary (vec operands,
+ *            NWORDS rule: smallest multiple of 208 (resp. 128) bits strictly greater than
+ *            bitlen(N), main.c:465-483).  The device arithmetic is the same either way.
+ * device: HIP device ordinal.                                                                 */
+int gecm_create(gecm_ctx **out, int device, const char *n_str, int digitbits);
+void gecm_destroy(gecm_ctx *ctx);
+
+typedef struct {
+    int digitbits;   /* 52 | 32                                   (avx_ecm.h:65-93)   */
+    int nwords;      /* NWORDS                                    (main.c:482)        */
+    int maxbits;     /* MAXBITS = DIGITBITS * NWORDS                                  */
+    int nbits;       /* bitlen(N)                                                     */
+    int dev_limbs;   /* 28-bit limbs per residue on the device                         */
+    int device;
+    uint64_t rho;    /* -N^-1 mod 2^DIGITBITS  (monty->vrho, main.c:636-640)           */
+} gecm_config;
+int gecm_get_config(const gecm_ctx *ctx, gecm_config *cfg);
+int gecm_device_name(gecm_ctx *ctx, char *buf, size_t len);
+/* "one" = R mod N in the reference limb format, single value (monty->one, main.c:633-634) */
+int gecm_get_one(const gecm_ctx *ctx, void *one_limbs);
+
+/* ---- L0: the five vector operators (avx_ecm.h:205-209) -------------------------------------
+ * Test-level exports: same semantics as vecmulmod52/vecsqrmod52/vecaddmod52/vecsubmod52/
+ * vec_simul_addsub52 (vecarith52.c:2438, 3317, 4550, 4684, 4877) and their 32-bit twins
+ * (vecarith.c:221, 889, 2806, 2870, 2726): inputs canonical, outputs canonical, Montgomery
+ * radix 2^(DIGITBITS*NWORDS).  `c` may alias `a` or `b`.  batch >= 1, any size.              */
+int gecm_vecmulmod(gecm_ctx *ctx, const void *a, const void *b, void *c, size_t batch);
+int gecm_vecsqrmod(gecm_ctx *ctx, const void *a, void *c, size_t batch);
+int gecm_vecaddmod(gecm_ctx *ctx, const void *a, const void *b, void *c, size_t batch);
+int gecm_vecsubmod(gecm_ctx *ctx, const void *a, const void *b, void *c, size_t batch);
+int gecm_vecaddsubmod(gecm_ctx *ctx, const void *a, const void *b, void *sum, void *diff, size_t batch);
+
+/* ---- L1 phase 0: curve construction (build_one_curve, ecm.c:1548-1803) ---------------------
+ * Suyama parametrisation from sigma[0..batch): the context computes X, Z (=1), s = (A+2)/4 on the
+ * host and uploads them.  sigma values must be >= 6 (the reference redraws below 6,
+ * ecm.c:1564-1570).  Returns GECM_OK, or 1 if some curve's setup inversion failed because
+ * gcd(denominator, N) > 1 (those lanes get X=Z=0 and are reported by gecm_bad_curves).       */
+int gecm_build_curves(gecm_ctx *ctx, const uint64_t *sigma, size_t batch);
+/* Alternative phase 0: caller supplies P=(X,Z) and s as vec operands (reference layout and
+ * Montgomery radix), e.g. the output of the reference's own build_one_curve.                 */
+int gecm_upload_points(gecm_ctx *ctx, const void *X, const void *Z, const void *s, size_t batch);
+
+/* ---- L1 phase 1: stage 1 (ecm_stage1, ecm.c:1806-1854) -------------------------------------
+ * P <- [prod of prime powers < B1] P for every curve of the batch.  Asynchronous: returns after
+ * the launch; gecm_sync waits.  B1 <= 10^8 (one prime range, ecm.c:1209-1234).                */
+int gecm_stage1(gecm_ctx *ctx, uint64_t B1);
+int gecm_sync(gecm_ctx *ctx);
+/* milliseconds of the last stage-1 kernel, from HIP events on the context's stream */
+double gecm_last_kernel_ms(const gecm_ctx *ctx);
+
+typedef struct {
+    uint64_t ptadds, ptdups;   /* ecm.c:441, 455; printed at ecm.c:1849-1850 */
+    uint64_t last_prime;       /* ecm.c:1849 */
+    uint64_t tape_len;
+} gecm_stage1_stats;
+int gecm_get_stage1_stats(const gecm_ctx *ctx, gecm_stage1_stats *st);
+
+/* P after stage 1 as vec operands (reference layout, Montgomery radix, canonical). */
+int gecm_download_points(gecm_ctx *ctx, void *X, void *Z);
+/* The de-Montgomeryised X*1, Z*1 the reference writes to save_b1.txt (ecm.c:1327-1331). */
+int gecm_download_points_plain(gecm_ctx *ctx, void *x, void *z);
+
+/* ---- save / factor path (ecm.c:1319-1388, check_factor ecm.c:2542-2557) --------------------
+ * Formats curve k's resume line exactly as ecm.c:1372-1380:
+ *   "METHOD=ECM; SIGMA=%lu; B1=%lu; N=0x%Zx; X=0x%Zx; Z=0x%Zx; PROGRAM=AVX-ECM;\n"
+ * from the last downloaded stage-1 result.  Returns the line length, or < 0.                  */
+int gecm_format_save_line(gecm_ctx *ctx, size_t k, char *buf, size_t buflen);
+/* gcd(Z_k, N) after stage 1 (ecm.c:1336-1344): returns 1 and the factor as a decimal string if
+ * 1 < g < N, else 0 (g == N is "no factor", ecm.c:2549-2553).                                 */
+int gecm_stage1_factor(gecm_ctx *ctx, size_t k, char *dec, size_t declen, int *is_prp);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

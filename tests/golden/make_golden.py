@@ -1,0 +1,144 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/ by RUNNING THE REFERENCE ITSELF.
+
+Runs only in the build container (needs /root/reference compiled by `make -C oracle ref harness`
+into oracle/_ref/).  The fixtures are data (inputs + outputs); no reference source is stored.
+
+  stage1.json : (N, sigma0, curves, B1[, B2]) -> the save_b1.txt lines the reference wrote
+                (ecm.c:1372-1380) + factor lines from ecm_results.txt (ecm.c:1362-1366, 1517-1520)
+  l0.json     : per-operator vectors (a, b, N -> mulmod, sqrmod, addmod, submod, addsub) from
+                the reference's vecarith52.c / vecarith.c via oracle/ref_l0_harness.c
+
+usage: python tests/golden/make_golden.py [--only stage1|l0] [--quick]
+"""
+import json, os, random, re, subprocess, sys, tempfile, hashlib
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REFDIR = os.path.join(ROOT, "oracle", "_ref")
+
+
+def rand_n(bits):
+    """SURVEY.md §8c/§8d input generator."""
+    return random.Random(bits).getrandbits(bits) | (1 << (bits - 1)) | 1
+
+
+
+def test_csh_case(sigma):
+    """(N, curves, B1, threads, B2, sigma) of the test.csh line that uses this sigma."""
+    for l in open("/root/reference/test.csh").read().splitlines():
+        f = l.split()
+        if len(f) >= 7 and f[6] == str(sigma):
+            return int(f[1]), int(f[3]), int(f[5]), int(f[6])
+    raise KeyError(sigma)
+
+
+
+def run_ref(digitbits, n_expr, curves, b1, b2, sigma, threads=1):
+    exe = os.path.join(REFDIR, "avx-ecm-%d" % digitbits)
+    with tempfile.TemporaryDirectory() as d:
+        cmd = [exe, str(n_expr), str(curves), str(b1), str(threads), str(b2), str(sigma)]
+        p = subprocess.run(cmd, cwd=d, capture_output=True, text=True, timeout=3600)
+        out = p.stdout
+        save = []
+        if os.path.exists(os.path.join(d, "save_b1.txt")):
+            save = open(os.path.join(d, "save_b1.txt")).read().splitlines()
+        res = []
+        if os.path.exists(os.path.join(d, "ecm_results.txt")):
+            res = [l for l in open(os.path.join(d, "ecm_results.txt")).read().splitlines() if l.strip()]
+    m = re.search(r"Choosing MAXBITS = (\d+), NWORDS = (\d+)", out)
+    cnt = re.search(r"with (\d+) point-adds and (\d+) point-doubles", out)
+    s2 = re.search(r"performed (\d+) pt-adds, (\d+) inversions, and (\d+) pair-muls", out)
+    t1 = re.search(r"Stage 1 took ([0-9.]+) seconds", out)
+    return {
+        "digitbits": digitbits, "N": str(n_expr), "curves": curves, "B1": b1, "B2": b2, "sigma0": sigma,
+        "maxbits": int(m.group(1)) if m else None, "nwords": int(m.group(2)) if m else None,
+        "ptadds": int(cnt.group(1)) if cnt else None, "ptdups": int(cnt.group(2)) if cnt else None,
+        "stage2_counts": [int(x) for x in s2.groups()] if s2 else None,
+        "stage1_seconds_container": float(t1.group(1)) if t1 else None,
+        "save_lines": save, "results_lines": res,
+        "save_sha256": hashlib.sha256(("\n".join(save) + "\n").encode()).hexdigest() if save else None,
+    }
+
+
+def gen_stage1(quick):
+    cases = []
+
+    def add(name, *a, **k):
+        print("stage1:", name, flush=True)
+        c = run_ref(*a, **k)
+        c["name"] = name
+        cases.append(c)
+
+    n415, n623, n831, n1023 = rand_n(415), rand_n(623), rand_n(831), rand_n(1023)
+    # stage-1-only runs: B2 = B1 disables stage 2 (main.c:548-552)
+    for b1 in (1000, 10000, 100000) + (() if quick else (1000000,)):
+        add("n415_b1_%d" % b1, 52, n415, 8, b1, b1, 1000)
+    for b1 in (1000, 10000) + (() if quick else (1000000,)):
+        add("n623_b1_%d" % b1, 52, n623, 8, b1, b1, 1000)
+        add("n831_b1_%d" % b1, 52, n831, 8, b1, b1, 1000)
+    for b1 in (1000, 10000) + (() if quick else (100000,)):
+        add("n1023_d32_b1_%d" % b1, 32, n1023, 16, b1, b1, 1000)
+    # K3: limb-width independence (same N through the 32-bit build)
+    add("n415_d32_b1_10000", 32, n415, 16, 10000, 10000, 1000)
+    # 64-bit sigma values (test_t35.csh style) and small / odd sizes
+    add("n415_bigsigma_b1_1000", 52, n415, 8, 1000, 1000, 11919771003873180376)
+    add("n200_b1_1000", 52, rand_n(200), 8, 1000, 1000, 42)
+    add("n64_b1_500", 52, rand_n(64), 8, 500, 500, 7)
+    # two batches of 8 (curves 16, 1 thread): sigma0..sigma0+15 unless a factor stops it early
+    add("n415_two_batches_b1_1000", 52, rand_n(414) , 16, 1000, 1000, 5000)
+    # KATs from test.csh / test_inputs.txt: K1 stage-1 factor, K2 stage-2 factor
+    if not quick:
+        n, b1, b2, sg = test_csh_case(7372562557)
+        add("K1", 52, n, 8, b1, b1, sg)
+        # K1's N has no small factors: 16 curves at a tiny B1 run as two batches of 8 (ecm.c:1151)
+        add("K1N_two_full_batches_b1_500", 52, n, 16, 500, 500, 100)
+        add("K1N_d32_b1_2000", 32, n, 16, 2000, 2000, 77)
+        n, b1, b2, sg = test_csh_case(3018506502)
+        add("K2", 52, n, 8, b1, b2, sg)
+        t35 = open("/root/reference/test_t35.csh").read().splitlines()[45].split()
+        add("T35_46", 52, int(t35[1]), 8, int(t35[3]), int(t35[5]), int(t35[6]))
+        # config 1 with a pinned sigma, B2 default 100*B1 given explicitly
+        add("config1_fib791", 52, "fib(791)/13/677/216416017", 8, 1000000, 100000000, 1000)
+    # stage-2 small cases (factor found or not; accumulators are not observable from the reference)
+    add("n415_b1_10000_b2_1e6", 52, n415, 8, 10000, 1000000, 1000)
+    json.dump(cases, open(os.path.join(HERE, "stage1.json"), "w"), indent=1)
+
+
+def gen_l0():
+    rng = random.Random(20261004)
+    out = []
+    for digitbits, veclen, sizes in ((52, 8, ((8, 415), (8, 412), (12, 623), (16, 831), (4, 200), (8, 400))),
+                                     (32, 16, ((32, 1023), (16, 415), (4, 127)))):
+        exe = os.path.join(REFDIR, "l0_harness-%d" % digitbits)
+        for nwords, bits in sizes:
+            n = rand_n(bits)
+            pairs = []
+            edge = [0, 1, 2, n - 1, n - 2, (n + 1) // 2, (n - 1) // 2, (1 << (bits - 1)) - 1]
+            for a in edge:
+                for b in (0, 1, n - 1, (n + 1) // 2):
+                    pairs.append((a, b))
+            while len(pairs) % veclen:
+                pairs.append((rng.randrange(n), rng.randrange(n)))
+            for _ in range(4 * veclen):
+                pairs.append((rng.randrange(n), rng.randrange(n)))
+            inp = "".join("%x %x\n" % p for p in pairs)
+            p = subprocess.run([exe, str(nwords), "%x" % n], input=inp, capture_output=True, text=True, check=True)
+            rows = [l.split() for l in p.stdout.splitlines()]
+            assert len(rows) == len(pairs), (len(rows), len(pairs))
+            out.append({"digitbits": digitbits, "nwords": nwords, "N": "%x" % n,
+                        "a": ["%x" % x[0] for x in pairs], "b": ["%x" % x[1] for x in pairs],
+                        "mul": [r[0] for r in rows], "sqr": [r[1] for r in rows],
+                        "add": [r[2] for r in rows], "sub": [r[3] for r in rows],
+                        "asum": [r[4] for r in rows], "adiff": [r[5] for r in rows]})
+            print("l0:", digitbits, nwords, bits, len(pairs), flush=True)
+    json.dump(out, open(os.path.join(HERE, "l0.json"), "w"), indent=0)
+
+
+if __name__ == "__main__":
+    only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else None
+    quick = "--quick" in sys.argv
+    if only in (None, "l0"):
+        gen_l0()
+    if only in (None, "stage1"):
+        gen_stage1(quick)
