@@ -354,12 +354,22 @@ int gecm_build_curves(gecm_ctx *c, const uint64_t *sigma, size_t batch)
         }
         invs[0] = inv;
     } else {
+        /* Some denominator shares a factor with N.  The reference ignores mpz_invert's return
+         * value (ecm.c:1745, 1759); GMP leaves the destination untouched on failure, so the
+         * reference goes on with the STALE operand: t2 = 16*u^3 (ecm.c:1718) in place of
+         * (16u^3v)^-1 and t1 = (v-u)^3(3u+v) (ecm.c:1637) in place of (v^3)^-1.  Reproduced here so
+         * that such curves still give the reference's residues bit for bit; the lane is also
+         * flagged (a non-invertible denominator means gcd(denominator, N) is a factor). */
         for (size_t i = 0; i < m; i++)
-            if (!mpl_invmod(&invs[i], &dens[i], &c->N)) { c->bad[i / 2] = 1; anybad = 1; invs[i].n = 0; }
+            if (!mpl_invmod(&invs[i], &dens[i], &c->N)) {
+                c->bad[i / 2] = 1;
+                anybad = 1;
+                if ((i & 1) == 0) { mpl_mul_u64(&t, &x3[i / 2], 16); mpl_mod(&invs[i], &t, &c->N); }
+                else invs[i] = num[i / 2];
+            }
     }
     for (size_t i = 0; i < batch; i++) {
         mpl_t A, X, Xm, Sm;
-        if (c->bad[i]) continue;   /* lanes stay zero */
         mpl_mulmod(&A, &num[i], &invs[2 * i], &c->N);          /* b = a / 16u^3v   ecm.c:1752-1753 */
         mpl_mulmod(&X, &x3[i], &invs[2 * i + 1], &c->N);       /* X = u^3 / v^3, Z = 1  ecm.c:1759-1761 */
         /* into Montgomery form (ecm.c:1763-1772), internal radix */

@@ -81,7 +81,8 @@ int gecm_vecaddsubmod(gecm_ctx *ctx, const void *a, const void *b, void *sum, vo
  * Suyama parametrisation from sigma[0..batch): the context computes X, Z (=1), s = (A+2)/4 on the
  * host and uploads them.  sigma values must be >= 6 (the reference redraws below 6,
  * ecm.c:1564-1570).  Returns GECM_OK, or 1 if some curve's setup inversion failed because
- * gcd(denominator, N) > 1 (those lanes get X=Z=0 and are reported by gecm_bad_curves).       */
+ * gcd(denominator, N) > 1; such lanes continue exactly as the reference does (it ignores
+ * mpz_invert's return value, ecm.c:1745, 1759, and goes on with the stale operand).           */
 int gecm_build_curves(gecm_ctx *ctx, const uint64_t *sigma, size_t batch);
 /* Alternative phase 0: caller supplies P=(X,Z) and s as vec operands (reference layout and
  * Montgomery radix), e.g. the output of the reference's own build_one_curve.                 */
