@@ -42,10 +42,113 @@ struct Fe {
     uint32_t v[NL];
 };
 
-__device__ __forceinline__ uint64_t mad64(uint32_t a, uint32_t b, uint64_t c)
+// ---- the multiply-accumulate chain --------------------------------------------------------
+// acc += sum x[k]*y[k] as K back-to-back v_mad_u64_u32 in ONE asm statement.  Inline asm on
+// purpose: from C++ LLVM reassociates the column sums into partial chains joined by 64-bit adds
+// (v_lshl_add_u64, one or two per column, +7% instructions) and stretches live ranges.  A serial
+// dependent chain costs nothing on gfx950 (a dependent v_mad_u64_u32 issues as fast as an
+// independent one: tools/mad_chain_ubench.hip), and grouping up to 8 per statement avoids the
+// s_nop the compiler pads after every asm statement.  The carry-out goes to vcc and is ignored
+// (28-bit limbs: the 64-bit column sum cannot overflow).  `_s`: y[] are wave-uniform (limbs of N)
+// and are read straight from SGPRs.
+template <int K>
+__device__ __forceinline__ void mad_chain_v(uint64_t &acc, const uint32_t (&x)[K], const uint32_t (&y)[K])
 {
-    // lowers to v_mad_u64_u32
-    return (uint64_t)a * (uint64_t)b + c;
+    if constexpr (K == 1) {
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(x[0]), "v"(y[0]) : "vcc");
+    }
+    else if constexpr (K == 2) {
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %3, %4, %0" : "+v"(acc) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]) : "vcc");
+    }
+    else if constexpr (K == 3) {
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_mad_u64_u32 %0, vcc, %5, %6, %0" : "+v"(acc) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]) : "vcc");
+    }
+    else if constexpr (K == 4) {
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_mad_u64_u32 %0, vcc, %5, %6, %0\n\tv_mad_u64_u32 %0, vcc, %7, %8, %0" : "+v"(acc) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]) : "vcc");
+    }
+    else if constexpr (K == 5) {
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_mad_u64_u32 %0, vcc, %5, %6, %0\n\tv_mad_u64_u32 %0, vcc, %7, %8, %0\n\tv_mad_u64_u32 %0, vcc, %9, %10, %0" : "+v"(acc) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]) : "vcc");
+    }
+    else if constexpr (K == 6) {
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_mad_u64_u32 %0, vcc, %5, %6, %0\n\tv_mad_u64_u32 %0, vcc, %7, %8, %0\n\tv_mad_u64_u32 %0, vcc, %9, %10, %0\n\tv_mad_u64_u32 %0, vcc, %11, %12, %0" : "+v"(acc) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]) : "vcc");
+    }
+    else if constexpr (K == 7) {
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_mad_u64_u32 %0, vcc, %5, %6, %0\n\tv_mad_u64_u32 %0, vcc, %7, %8, %0\n\tv_mad_u64_u32 %0, vcc, %9, %10, %0\n\tv_mad_u64_u32 %0, vcc, %11, %12, %0\n\tv_mad_u64_u32 %0, vcc, %13, %14, %0" : "+v"(acc) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]) : "vcc");
+    }
+    else if constexpr (K == 8) {
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_mad_u64_u32 %0, vcc, %5, %6, %0\n\tv_mad_u64_u32 %0, vcc, %7, %8, %0\n\tv_mad_u64_u32 %0, vcc, %9, %10, %0\n\tv_mad_u64_u32 %0, vcc, %11, %12, %0\n\tv_mad_u64_u32 %0, vcc, %13, %14, %0\n\tv_mad_u64_u32 %0, vcc, %15, %16, %0" : "+v"(acc) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]), "v"(x[7]), "v"(y[7]) : "vcc");
+    }
+}
+
+template <int K>
+__device__ __forceinline__ void mad_chain_s(uint64_t &acc, const uint32_t (&x)[K], const uint32_t (&y)[K])
+{
+    if constexpr (K == 1) {
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(x[0]), "s"(y[0]) : "vcc");
+    }
+    else if constexpr (K == 2) {
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %3, %4, %0" : "+v"(acc) : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]) : "vcc");
+    }
+    else if constexpr (K == 3) {
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_mad_u64_u32 %0, vcc, %5, %6, %0" : "+v"(acc) : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]) : "vcc");
+    }
+    else if constexpr (K == 4) {
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_mad_u64_u32 %0, vcc, %5, %6, %0\n\tv_mad_u64_u32 %0, vcc, %7, %8, %0" : "+v"(acc) : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]) : "vcc");
+    }
+    else if constexpr (K == 5) {
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_mad_u64_u32 %0, vcc, %5, %6, %0\n\tv_mad_u64_u32 %0, vcc, %7, %8, %0\n\tv_mad_u64_u32 %0, vcc, %9, %10, %0" : "+v"(acc) : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]), "v"(x[4]), "s"(y[4]) : "vcc");
+    }
+    else if constexpr (K == 6) {
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_mad_u64_u32 %0, vcc, %5, %6, %0\n\tv_mad_u64_u32 %0, vcc, %7, %8, %0\n\tv_mad_u64_u32 %0, vcc, %9, %10, %0\n\tv_mad_u64_u32 %0, vcc, %11, %12, %0" : "+v"(acc) : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]), "v"(x[4]), "s"(y[4]), "v"(x[5]), "s"(y[5]) : "vcc");
+    }
+    else if constexpr (K == 7) {
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_mad_u64_u32 %0, vcc, %5, %6, %0\n\tv_mad_u64_u32 %0, vcc, %7, %8, %0\n\tv_mad_u64_u32 %0, vcc, %9, %10, %0\n\tv_mad_u64_u32 %0, vcc, %11, %12, %0\n\tv_mad_u64_u32 %0, vcc, %13, %14, %0" : "+v"(acc) : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]), "v"(x[4]), "s"(y[4]), "v"(x[5]), "s"(y[5]), "v"(x[6]), "s"(y[6]) : "vcc");
+    }
+    else if constexpr (K == 8) {
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_mad_u64_u32 %0, vcc, %5, %6, %0\n\tv_mad_u64_u32 %0, vcc, %7, %8, %0\n\tv_mad_u64_u32 %0, vcc, %9, %10, %0\n\tv_mad_u64_u32 %0, vcc, %11, %12, %0\n\tv_mad_u64_u32 %0, vcc, %13, %14, %0\n\tv_mad_u64_u32 %0, vcc, %15, %16, %0" : "+v"(acc) : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]), "v"(x[4]), "s"(y[4]), "v"(x[5]), "s"(y[5]), "v"(x[6]), "s"(y[6]), "v"(x[7]), "s"(y[7]) : "vcc");
+    }
+}
+
+template <int K> struct IC { static constexpr int value = K; };
+template <int I0, int I1, class F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (I0 < I1) {
+        f(IC<I0>{});
+        static_for<I0 + 1, I1>(f);
+    }
+}
+
+// acc += sum_{i in [I0,I1)} a[i] * b[C-i]
+template <int C, int I0, int I1, int NA, int NB>
+__device__ __forceinline__ void col_vv(uint64_t &acc, const uint32_t (&a)[NA], const uint32_t (&b)[NB])
+{
+    constexpr int K = I1 - I0;
+    if constexpr (K > 8) {
+        col_vv<C, I0, I0 + 8>(acc, a, b);
+        col_vv<C, I0 + 8, I1>(acc, a, b);
+    } else if constexpr (K > 0) {
+        uint32_t x[K], y[K];
+#pragma unroll
+        for (int k = 0; k < K; k++) { x[k] = a[I0 + k]; y[k] = b[C - I0 - k]; }
+        mad_chain_v<K>(acc, x, y);
+    }
+}
+
+// acc += sum_{i in [I0,I1)} q[i] * n[C-i]   (n wave-uniform)
+template <int C, int I0, int I1, int NA, int NB>
+__device__ __forceinline__ void col_vs(uint64_t &acc, const uint32_t (&q)[NA], const uint32_t (&n)[NB])
+{
+    constexpr int K = I1 - I0;
+    if constexpr (K > 8) {
+        col_vs<C, I0, I0 + 8>(acc, q, n);
+        col_vs<C, I0 + 8, I1>(acc, q, n);
+    } else if constexpr (K > 0) {
+        uint32_t x[K], y[K];
+#pragma unroll
+        for (int k = 0; k < K; k++) { x[k] = q[I0 + k]; y[k] = n[C - I0 - k]; }
+        mad_chain_s<K>(acc, x, y);
+    }
 }
 
 // r = a*b/R mod N (lazy: r < 0.675K, limbs < 2^28).  r may alias a or b.
@@ -55,25 +158,21 @@ __device__ __forceinline__ void fe_mul(Fe<NL> &r, const Fe<NL> &a, const Fe<NL> 
     uint32_t q[NL];
     Fe<NL> o;
     uint64_t acc = 0;
-#pragma unroll
-    for (int c = 0; c < NL; c++) {
-#pragma unroll
-        for (int i = 0; i <= c; i++) acc = mad64(a.v[i], b.v[c - i], acc);
-#pragma unroll
-        for (int i = 0; i < c; i++) acc = mad64(q[i], m.n[c - i], acc);
+    static_for<0, NL>([&](auto ic) {
+        constexpr int c = decltype(ic)::value;
+        col_vv<c, 0, c + 1>(acc, a.v, b.v);
+        col_vs<c, 0, c>(acc, q, m.n);
         q[c] = ((uint32_t)acc * m.rho) & GECM_LIMB_MASK;
-        acc = mad64(q[c], m.n[0], acc);
+        col_vs<c, c, c + 1>(acc, q, m.n);
         acc >>= GECM_LIMB_BITS;
-    }
-#pragma unroll
-    for (int c = NL; c < 2 * NL; c++) {
-#pragma unroll
-        for (int i = c - NL + 1; i < NL; i++) acc = mad64(a.v[i], b.v[c - i], acc);
-#pragma unroll
-        for (int i = c - NL + 1; i < NL; i++) acc = mad64(q[i], m.n[c - i], acc);
+    });
+    static_for<NL, 2 * NL>([&](auto ic) {
+        constexpr int c = decltype(ic)::value;
+        col_vv<c, c - NL + 1, NL>(acc, a.v, b.v);
+        col_vs<c, c - NL + 1, NL>(acc, q, m.n);
         o.v[c - NL] = (c == 2 * NL - 1) ? (uint32_t)acc : ((uint32_t)acc & GECM_LIMB_MASK);
         acc >>= GECM_LIMB_BITS;
-    }
+    });
     r = o;
 }
 
@@ -88,27 +187,23 @@ __device__ __forceinline__ void fe_sqr(Fe<NL> &r, const Fe<NL> &a, const ModK<NL
 #pragma unroll
     for (int i = 0; i < NL; i++) a2[i] = a.v[i] << 1;
     uint64_t acc = 0;
-#pragma unroll
-    for (int c = 0; c < NL; c++) {
-#pragma unroll
-        for (int i = 0; 2 * i < c; i++) acc = mad64(a.v[i], a2[c - i], acc);
-        if ((c & 1) == 0) acc = mad64(a.v[c / 2], a.v[c / 2], acc);
-#pragma unroll
-        for (int i = 0; i < c; i++) acc = mad64(q[i], m.n[c - i], acc);
+    static_for<0, NL>([&](auto ic) {
+        constexpr int c = decltype(ic)::value;
+        col_vv<c, 0, (c + 1) / 2>(acc, a.v, a2);                     // i < c-i
+        if constexpr ((c & 1) == 0) col_vv<c, c / 2, c / 2 + 1>(acc, a.v, a.v);
+        col_vs<c, 0, c>(acc, q, m.n);
         q[c] = ((uint32_t)acc * m.rho) & GECM_LIMB_MASK;
-        acc = mad64(q[c], m.n[0], acc);
+        col_vs<c, c, c + 1>(acc, q, m.n);
         acc >>= GECM_LIMB_BITS;
-    }
-#pragma unroll
-    for (int c = NL; c < 2 * NL; c++) {
-#pragma unroll
-        for (int i = c - NL + 1; 2 * i < c; i++) acc = mad64(a.v[i], a2[c - i], acc);
-        if ((c & 1) == 0 && c / 2 < NL) acc = mad64(a.v[c / 2], a.v[c / 2], acc);
-#pragma unroll
-        for (int i = c - NL + 1; i < NL; i++) acc = mad64(q[i], m.n[c - i], acc);
+    });
+    static_for<NL, 2 * NL>([&](auto ic) {
+        constexpr int c = decltype(ic)::value;
+        col_vv<c, c - NL + 1, (c + 1) / 2>(acc, a.v, a2);
+        if constexpr ((c & 1) == 0 && c / 2 < NL) col_vv<c, c / 2, c / 2 + 1>(acc, a.v, a.v);
+        col_vs<c, c - NL + 1, NL>(acc, q, m.n);
         o.v[c - NL] = (c == 2 * NL - 1) ? (uint32_t)acc : ((uint32_t)acc & GECM_LIMB_MASK);
         acc >>= GECM_LIMB_BITS;
-    }
+    });
     r = o;
 }
 
