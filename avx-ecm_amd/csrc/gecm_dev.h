@@ -48,6 +48,20 @@ int gecm_dev_download_plain(gecm_dev *d, uint32_t *x, uint32_t *z);
 int gecm_dev_l0(gecm_dev *d, int op, const uint32_t *a, const uint32_t *b, uint32_t *c, uint32_t *dd,
                 size_t count, const uint32_t *fix);
 
+/* ---- stage 2 (csrc/gecm_stage2.hpp) ----
+ * r3 = R^3 mod N (28-bit limbs); inv_iters = iteration count of the device inversion. */
+int gecm_dev_set_s2const(gecm_dev *d, const uint32_t *r3, uint32_t inv_iters);
+/* ecm_stage2_init: baby-step table (npb entries, X/Z normalised), Pd = [D]Q, acc = one.
+ * keep: bitmap over j in [0, umax], bit set iff j is stored.  L = ring half-size (2L giant steps). */
+int gecm_dev_s2_init(gecm_dev *d, const uint32_t *keep, size_t keep_words, uint32_t umax, uint32_t D,
+                     uint32_t npb, uint32_t L);
+/* ecm_stage2_pair for one range: steps = nsteps pairs (pa, pb); pa = 0xffffffff -> window shift. */
+int gecm_dev_s2_pair(gecm_dev *d, const uint32_t *steps, uint32_t nsteps, uint32_t U, uint32_t L, uint32_t D,
+                     uint64_t A0);
+/* canonical Montgomery-form accumulator and the failed-inversion gcd records ([limb][curve]) */
+int gecm_dev_s2_download(gecm_dev *d, uint32_t *acc, uint32_t *fail);
+size_t gecm_dev_s2_bytes(int nl, size_t ncurves, uint32_t npb, uint32_t L);
+
 #ifdef __cplusplus
 }
 #endif

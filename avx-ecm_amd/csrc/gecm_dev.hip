@@ -39,6 +39,12 @@ struct gecm_dev {
     uint32_t *dX = nullptr, *dZ = nullptr, *dS = nullptr, *dT0 = nullptr, *dT1 = nullptr;
     uint32_t *dTape = nullptr;
     size_t tape_len = 0, tape_cap = 0;
+    // stage 2
+    std::vector<uint32_t> r3;
+    uint32_t inv_iters = 0;
+    uint32_t *dPbX = nullptr, *dBlk = nullptr, *dPd = nullptr, *dAcc = nullptr, *dFail = nullptr, *dKeep = nullptr;
+    uint32_t *dPa = nullptr, *dSteps = nullptr;
+    size_t s2_npb = 0, s2_L = 0, s2_stride = 0, steps_cap = 0, keep_cap = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_ms = 0.f;
@@ -58,7 +64,9 @@ static gecm_modconst modconst(const gecm_dev *d)
     mc.n = d->n.data();
     mc.kp = d->kp.data();
     mc.one = d->one.data();
+    mc.r3 = d->r3.empty() ? d->one.data() : d->r3.data();
     mc.rho = d->rho;
+    mc.inv_iters = d->inv_iters;
     return mc;
 }
 
@@ -94,19 +102,30 @@ extern "C" int gecm_dev_open(gecm_dev **out, int device, int nl, const uint32_t 
 
 static void free_state(gecm_dev *d)
 {
-    hipFree(d->dX); hipFree(d->dZ); hipFree(d->dS); hipFree(d->dT0); hipFree(d->dT1);
+    (void)hipFree(d->dX); (void)hipFree(d->dZ); (void)hipFree(d->dS); (void)hipFree(d->dT0); (void)hipFree(d->dT1);
     d->dX = d->dZ = d->dS = d->dT0 = d->dT1 = nullptr;
+}
+
+static void free_s2(gecm_dev *d)
+{
+    (void)hipFree(d->dPbX); (void)hipFree(d->dBlk); (void)hipFree(d->dPd); (void)hipFree(d->dAcc);
+    (void)hipFree(d->dFail); (void)hipFree(d->dPa);
+    d->dPbX = d->dBlk = d->dPd = d->dAcc = d->dFail = d->dPa = nullptr;
+    d->s2_npb = d->s2_L = d->s2_stride = 0;
 }
 
 extern "C" void gecm_dev_close(gecm_dev *d)
 {
     if (!d) return;
-    hipSetDevice(d->device);
+    (void)hipSetDevice(d->device);
     free_state(d);
-    hipFree(d->dTape);
-    if (d->ev0) hipEventDestroy(d->ev0);
-    if (d->ev1) hipEventDestroy(d->ev1);
-    if (d->stream) hipStreamDestroy(d->stream);
+    free_s2(d);
+    (void)hipFree(d->dKeep);
+    (void)hipFree(d->dSteps);
+    (void)hipFree(d->dTape);
+    if (d->ev0) (void)hipEventDestroy(d->ev0);
+    if (d->ev1) (void)hipEventDestroy(d->ev1);
+    if (d->stream) (void)hipStreamDestroy(d->stream);
     delete d;
 }
 
@@ -172,7 +191,7 @@ extern "C" int gecm_dev_set_tape(gecm_dev *d, const uint8_t *tape, size_t len)
     HIPCHK(hipSetDevice(d->device));
     size_t words = (len + 3) / 4 + 1;
     if (words > d->tape_cap) {
-        hipFree(d->dTape);
+        (void)hipFree(d->dTape);
         d->dTape = nullptr;
         HIPCHK(hipMalloc(&d->dTape, words * 4));
         d->tape_cap = words;
@@ -277,5 +296,125 @@ extern "C" int gecm_dev_l0(gecm_dev *d, int op, const uint32_t *a, const uint32_
         if (download_soa(d, dd, d->dT1)) return -1;
     HIPCHK(hipStreamSynchronize(d->stream));
     (void)keep;
+    return 0;
+}
+
+// ---------------------------------------------------------------- stage 2
+extern "C" int gecm_dev_set_s2const(gecm_dev *d, const uint32_t *r3, uint32_t inv_iters)
+{
+    d->r3.assign(r3, r3 + d->nl);
+    d->inv_iters = inv_iters;
+    return 0;
+}
+
+extern "C" size_t gecm_dev_s2_bytes(int nl, size_t ncurves, uint32_t npb, uint32_t L)
+{
+    size_t stride = (ncurves + 63) / 64 * 64;
+    size_t coord = (size_t)nl * stride * 4;
+    return coord * ((size_t)npb + 3 * 32 + 2 + 2 + 3 * 2 * (size_t)L + 2 * (size_t)L);
+}
+
+extern "C" int gecm_dev_s2_init(gecm_dev *d, const uint32_t *keep, size_t keep_words, uint32_t umax, uint32_t D,
+                                uint32_t npb, uint32_t L)
+{
+    HIPCHK(hipSetDevice(d->device));
+    if (!d->stride || d->r3.empty()) {
+        g_err = "gecm_dev_s2_init: no curves or stage-2 constants not set";
+        return -2;
+    }
+    const size_t coord = (size_t)d->nl * d->stride * sizeof(uint32_t);
+    if (d->s2_npb != npb || d->s2_L != L || d->s2_stride != d->stride) {
+        free_s2(d);
+        HIPCHK(hipMalloc(&d->dPbX, coord * npb));
+        HIPCHK(hipMalloc(&d->dBlk, coord * 3 * 32));             // bx, bz, bp: S2_BLK entries each
+        HIPCHK(hipMalloc(&d->dPd, coord * 2));
+        HIPCHK(hipMalloc(&d->dAcc, coord));
+        HIPCHK(hipMalloc(&d->dFail, coord));
+        HIPCHK(hipMalloc(&d->dPa, coord * (3 * 2 * (size_t)L + 2 * (size_t)L)));   // PaX, PaZ, PaI, prefix scratch
+        d->s2_npb = npb; d->s2_L = L; d->s2_stride = d->stride;
+    }
+    if (keep_words > d->keep_cap) {
+        (void)hipFree(d->dKeep);
+        d->dKeep = nullptr;
+        HIPCHK(hipMalloc(&d->dKeep, keep_words * 4));
+        d->keep_cap = keep_words;
+    }
+    HIPCHK(hipMemcpyAsync(d->dKeep, keep, keep_words * 4, hipMemcpyHostToDevice, d->stream));
+    HIPCHK(hipMemsetAsync(d->dFail, 0, coord, d->stream));
+    HIPCHK(hipMemsetAsync(d->dPbX, 0, coord, d->stream));        // entry 0 (unused) defined
+    gecm_s2_init_args a;
+    a.X = d->dX; a.Z = d->dZ; a.S = d->dS;
+    a.PbX = d->dPbX;
+    a.bx = d->dBlk; a.bz = d->dBlk + (coord / 4) * 32; a.bp = d->dBlk + (coord / 4) * 64;
+    a.PdX = d->dPd; a.PdZ = d->dPd + coord / 4;
+    a.acc = d->dAcc; a.fail = d->dFail; a.keep = d->dKeep;
+    a.umax = umax; a.D = D; a.stride = d->stride;
+    gecm_modconst mc = modconst(d);
+    HIPCHK(hipEventRecord(d->ev0, d->stream));
+    switch (d->nl) {
+#define X(n)                                             \
+    case n:                                              \
+        gecm_launch_s2_init_##n(d->stream, &mc, &a);     \
+        break;
+        GECM_NL_LIST(X)
+#undef X
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(d->ev1, d->stream));
+    d->timed = true;
+    return 0;
+}
+
+extern "C" int gecm_dev_s2_pair(gecm_dev *d, const uint32_t *steps, uint32_t nsteps, uint32_t U, uint32_t L, uint32_t D,
+                                uint64_t A0)
+{
+    HIPCHK(hipSetDevice(d->device));
+    if (!d->dPbX || d->s2_L != L) {
+        g_err = "gecm_dev_s2_pair: stage-2 init has not run (or L changed)";
+        return -2;
+    }
+    const size_t coord = (size_t)d->nl * d->stride * sizeof(uint32_t);
+    size_t words = (size_t)nsteps * 2 + 2;
+    if (words > d->steps_cap) {
+        (void)hipFree(d->dSteps);
+        d->dSteps = nullptr;
+        HIPCHK(hipMalloc(&d->dSteps, words * 4));
+        d->steps_cap = words;
+    }
+    if (nsteps) HIPCHK(hipMemcpyAsync(d->dSteps, steps, (size_t)nsteps * 8, hipMemcpyHostToDevice, d->stream));
+    gecm_s2_pair_args a;
+    a.X = d->dX; a.Z = d->dZ; a.S = d->dS; a.PbX = d->dPbX;
+    a.PdX = d->dPd; a.PdZ = d->dPd + coord / 4;
+    const size_t ring = 2 * (size_t)L;
+    a.PaX = d->dPa; a.PaZ = d->dPa + (coord / 4) * ring; a.PaI = d->dPa + (coord / 4) * 2 * ring;
+    a.bp = d->dPa + (coord / 4) * 3 * ring;
+    a.acc = d->dAcc; a.fail = d->dFail; a.steps = d->dSteps;
+    a.nsteps = nsteps; a.U = U; a.L = L; a.D = D; a.A0 = A0; a.stride = d->stride;
+    gecm_modconst mc = modconst(d);
+    HIPCHK(hipEventRecord(d->ev0, d->stream));
+    switch (d->nl) {
+#define X(n)                                             \
+    case n:                                              \
+        gecm_launch_s2_pair_##n(d->stream, &mc, &a);     \
+        break;
+        GECM_NL_LIST(X)
+#undef X
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(d->ev1, d->stream));
+    d->timed = true;
+    return 0;
+}
+
+extern "C" int gecm_dev_s2_download(gecm_dev *d, uint32_t *acc, uint32_t *fail)
+{
+    HIPCHK(hipSetDevice(d->device));
+    if (!d->dAcc) {
+        g_err = "gecm_dev_s2_download: no stage-2 state";
+        return -2;
+    }
+    if (download_soa(d, acc, d->dAcc)) return -1;
+    if (fail && download_soa(d, fail, d->dFail)) return -1;
+    HIPCHK(hipStreamSynchronize(d->stream));
     return 0;
 }

@@ -4,6 +4,7 @@
 #include "gecm_dev.h"
 #include "gecm_launch.h"
 #include "gecm_curve.hpp"
+#include "gecm_stage2.hpp"
 #include <hip/hip_runtime.h>
 
 #ifndef GECM_NL
@@ -83,6 +84,19 @@ k_l0(int op, const uint32_t *__restrict__ A, const uint32_t *__restrict__ B, uin
 }
 
 
+// ---------------------------------------------------------------- stage 2
+template <int NL>
+__global__ void __launch_bounds__(64, 2) k_s2_init(S2InitArgs a, S2Const<NL> k)
+{
+    s2_init<NL>(a, k, (size_t)blockIdx.x * 64 + threadIdx.x);
+}
+
+template <int NL>
+__global__ void __launch_bounds__(64, 2) k_s2_pair(S2PairArgs a, S2Const<NL> k)
+{
+    s2_pair<NL>(a, k, (size_t)blockIdx.x * 64 + threadIdx.x);
+}
+
 // ---------------------------------------------------------------- launchers (C linkage)
 template <int NL>
 static ModArgs<NL> make_args(const gecm_modconst *mc)
@@ -95,6 +109,21 @@ static ModArgs<NL> make_args(const gecm_modconst *mc)
     }
     a.m.rho = mc->rho;
     return a;
+}
+
+template <int NL>
+static S2Const<NL> make_s2(const gecm_modconst *mc)
+{
+    S2Const<NL> k;
+    for (int i = 0; i < NL; i++) {
+        k.m.n[i] = mc->n[i];
+        k.m.kp[i] = mc->kp[i];
+        k.one.v[i] = mc->one[i];
+        k.r3.v[i] = mc->r3[i];
+    }
+    k.m.rho = mc->rho;
+    k.inv_iters = mc->inv_iters;
+    return k;
 }
 
 #define CAT_(a, b) a##b
@@ -124,4 +153,24 @@ extern "C" void CAT(gecm_launch_l0_, GECM_NL)(void *stream, const gecm_modconst 
     for (int i = 0; i < GECM_NL; i++) f.v[i] = fix[i];
     hipLaunchKernelGGL(k_l0<GECM_NL>, dim3((unsigned)(stride / 64)), dim3(64), 0, (hipStream_t)stream, op, A, B, C,
                        D, stride, make_args<GECM_NL>(mc), f);
+}
+
+extern "C" void CAT(gecm_launch_s2_init_, GECM_NL)(void *stream, const gecm_modconst *mc, const gecm_s2_init_args *h)
+{
+    S2InitArgs a;
+    a.X = h->X; a.Z = h->Z; a.S = h->S; a.PbX = h->PbX; a.bx = h->bx; a.bz = h->bz; a.bp = h->bp;
+    a.PdX = h->PdX; a.PdZ = h->PdZ; a.acc = h->acc; a.fail = h->fail; a.keep = h->keep;
+    a.umax = h->umax; a.D = h->D; a.stride = h->stride;
+    hipLaunchKernelGGL(k_s2_init<GECM_NL>, dim3((unsigned)(h->stride / 64)), dim3(64), 0, (hipStream_t)stream, a,
+                       make_s2<GECM_NL>(mc));
+}
+
+extern "C" void CAT(gecm_launch_s2_pair_, GECM_NL)(void *stream, const gecm_modconst *mc, const gecm_s2_pair_args *h)
+{
+    S2PairArgs a;
+    a.X = h->X; a.Z = h->Z; a.S = h->S; a.PbX = h->PbX; a.PdX = h->PdX; a.PdZ = h->PdZ;
+    a.PaX = h->PaX; a.PaZ = h->PaZ; a.PaI = h->PaI; a.bp = h->bp; a.acc = h->acc; a.fail = h->fail;
+    a.steps = h->steps; a.nsteps = h->nsteps; a.U = h->U; a.L = h->L; a.D = h->D; a.A0 = h->A0; a.stride = h->stride;
+    hipLaunchKernelGGL(k_s2_pair<GECM_NL>, dim3((unsigned)(h->stride / 64)), dim3(64), 0, (hipStream_t)stream, a,
+                       make_s2<GECM_NL>(mc));
 }

@@ -11,9 +11,26 @@ extern "C" {
 #define GECM_NL_LIST(X) X(8) X(12) X(15) X(19) X(23) X(26) X(30) X(34) X(37)
 
 typedef struct {
-    const uint32_t *n, *kp, *one;
-    uint32_t rho;
+    const uint32_t *n, *kp, *one, *r3;
+    uint32_t rho, inv_iters;
 } gecm_modconst;
+
+typedef struct {
+    const uint32_t *X, *Z, *S;
+    uint32_t *PbX, *bx, *bz, *bp, *PdX, *PdZ, *acc, *fail;
+    const uint32_t *keep;
+    uint32_t umax, D;
+    size_t stride;
+} gecm_s2_init_args;
+
+typedef struct {
+    const uint32_t *X, *Z, *S, *PbX, *PdX, *PdZ;
+    uint32_t *PaX, *PaZ, *PaI, *bp, *acc, *fail;
+    const uint32_t *steps;
+    uint32_t nsteps, U, L, D;
+    uint64_t A0;
+    size_t stride;
+} gecm_s2_pair_args;
 
 #define GECM_DECL(nl)                                                                                     \
     void gecm_launch_stage1_##nl(void *stream, const gecm_modconst *mc, const uint32_t *tape,             \
@@ -23,7 +40,9 @@ typedef struct {
                                     const uint32_t *Z, uint32_t *ox, uint32_t *oz, size_t stride);        \
     void gecm_launch_l0_##nl(void *stream, const gecm_modconst *mc, int op, const uint32_t *A,            \
                              const uint32_t *B, uint32_t *C, uint32_t *D, size_t stride,                  \
-                             const uint32_t *fix);
+                             const uint32_t *fix);                                                        \
+    void gecm_launch_s2_init_##nl(void *stream, const gecm_modconst *mc, const gecm_s2_init_args *h);     \
+    void gecm_launch_s2_pair_##nl(void *stream, const gecm_modconst *mc, const gecm_s2_pair_args *h);
 GECM_NL_LIST(GECM_DECL)
 #undef GECM_DECL
 

@@ -1,0 +1,411 @@
+// gecm_stage2.hpp — stage 2 (standard continuation) on the device.
+//
+// Replaces, for the GPU:
+//   next_pt_vec                 ecm.c:886-976    binary Montgomery ladder, uniform multiplier
+//   ecm_stage2_init             ecm.c:2201-2340  baby-step table Pb[map[j]], j <= U*D, gcd(j,D)=1
+//   batch_invert_pt_inplace     ecm.c:1869-2001  Montgomery's trick + one inversion
+//   batch_invert_pt_to_bignum   ecm.c:2003-2136
+//   ecm_stage2_pair             ecm.c:2342-2540  giant-step window + CROSS_PRODUCT_INV (ecm.c:1857-1859)
+//
+// One curve per lane as in stage 1; control flow is wave-uniform (the pair map, the keep-bitmap of
+// the baby steps and the ladder bits are the same for every curve).  Tables live in HBM,
+// [entry][limb][curve], so every access is a coalesced 256-byte row per limb.
+//
+// Differences from the reference that do not change any result (inverses mod N are unique and
+// the accumulator is a product in a commutative ring):
+//   * the per-lane host mpz_invert (ecm.c:1919-1950, 2054-2085) becomes a fixed-iteration binary
+//     inversion on the device (fe_invert); a non-invertible product records gcd(product, N) per
+//     curve instead of writing it into stg2acc (ecm.c:1927-1939);
+//   * the baby-step table is normalised in blocks of S2_BLK entries (one inversion per block)
+//     rather than in one 7.7k-entry pass, so only the normalised X of each entry is kept in HBM;
+//   * the giant-step window is a ring (no copies on a window shift, ecm.c:2461-2469).
+#pragma once
+#include "gecm_curve.hpp"
+
+#define S2_BLK 32
+
+template <int NL>
+struct S2Const {
+    ModK<NL> m;
+    Fe<NL> one;   // R mod N
+    Fe<NL> r3;    // R^3 mod N  (plain inverse -> Montgomery form of the inverse)
+    uint32_t inv_iters;   // 2 * bitlen(N)
+};
+
+// entry `e` of a table [entry][limb][curve]
+template <int NL>
+__device__ __forceinline__ void tb_load(Fe<NL> &r, const uint32_t *__restrict__ base, size_t stride, size_t idx, size_t e)
+{
+    fe_load(r, base + e * (size_t)NL * stride, stride, idx);
+}
+template <int NL>
+__device__ __forceinline__ void tb_store(uint32_t *__restrict__ base, size_t stride, size_t idx, size_t e, const Fe<NL> &r)
+{
+    fe_store(base + e * (size_t)NL * stride, stride, idx, r);
+}
+
+// ---- exact helpers on fully normalised values ----------------------------------------------
+// r = a - b, returns borrow (1 if a < b); limbs normalised in and out (result mod 2^(28 NL))
+template <int NL>
+__device__ __forceinline__ uint32_t fe_sub_borrow(Fe<NL> &r, const Fe<NL> &a, const Fe<NL> &b)
+{
+    uint32_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        uint32_t d = a.v[i] - b.v[i] - borrow;
+        borrow = d >> 31;
+        r.v[i] = d & GECM_LIMB_MASK;
+    }
+    return borrow;
+}
+template <int NL>
+__device__ __forceinline__ void fe_add_carry(Fe<NL> &r, const Fe<NL> &a, const uint32_t (&b)[NL])
+{
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        uint32_t t = a.v[i] + b[i] + c;
+        c = t >> GECM_LIMB_BITS;
+        r.v[i] = (i == NL - 1) ? t : (t & GECM_LIMB_MASK);
+    }
+}
+template <int NL>
+__device__ __forceinline__ void fe_shr1(Fe<NL> &r)
+{
+#pragma unroll
+    for (int i = 0; i < NL - 1; i++) r.v[i] = (r.v[i] >> 1) | ((r.v[i + 1] & 1u) << (GECM_LIMB_BITS - 1));
+    r.v[NL - 1] >>= 1;
+}
+template <int NL>
+__device__ __forceinline__ void fe_select(Fe<NL> &r, bool c, const Fe<NL> &a, const Fe<NL> &b)
+{
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.v[i] = c ? a.v[i] : b.v[i];
+}
+
+// x^-1 mod N for canonical x (plain integers, not Montgomery form), fixed iteration count
+// (branch-free per lane).  Invariants: x1*x = u, x2*x = v (mod N); v stays odd; at the end u = 0
+// and v = gcd(x, N).  Returns true iff the inverse exists; g receives the gcd.
+template <int NL>
+__device__ __noinline__ bool fe_invert(Fe<NL> &r, Fe<NL> &g, const Fe<NL> &x, const ModK<NL> &m, uint32_t iters)
+{
+    Fe<NL> u = x, v, x1, x2, n;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        v.v[i] = m.n[i];
+        n.v[i] = m.n[i];
+        x1.v[i] = (i == 0) ? 1u : 0u;
+        x2.v[i] = 0u;
+    }
+    for (uint32_t it = 0; it < iters; it++) {
+        bool odd = (u.v[0] & 1u) != 0;
+        Fe<NL> d, e, t, tn;
+        uint32_t lt = fe_sub_borrow(d, u, v);      // d = u - v
+        fe_sub_borrow(e, v, u);                     // e = v - u
+        bool sw = odd && lt;
+        uint32_t bt = fe_sub_borrow(t, x1, x2);    // t = x1 - x2 mod N
+        fe_add_carry(tn, t, m.n);
+        tn.v[NL - 1] &= GECM_LIMB_MASK;             // wrapped sum (only used when bt)
+        fe_select(t, bt != 0, tn, t);
+        // negation of t mod N for the swapped case: N - t (t != 0) or 0
+        Fe<NL> nt;
+        fe_sub_borrow(nt, n, t);
+        bool tz = true;
+#pragma unroll
+        for (int i = 0; i < NL; i++) tz = tz && (t.v[i] == 0);
+        fe_select(nt, tz, t, nt);
+        // apply
+        Fe<NL> nu, nv, nx1, nx2;
+        fe_select(nu, sw, e, d);          // u - v or v - u
+        fe_select(nu, odd, nu, u);
+        fe_select(nv, sw, u, v);
+        fe_select(nx1, sw, nt, t);
+        fe_select(nx1, odd, nx1, x1);
+        fe_select(nx2, sw, x1, x2);
+        u = nu; v = nv; x1 = nx1; x2 = nx2;
+        // halve u, halve x1 mod N
+        fe_shr1(u);
+        Fe<NL> xo;
+        fe_add_carry(xo, x1, m.n);
+        bool xodd = (x1.v[0] & 1u) != 0;
+        fe_select(x1, xodd, xo, x1);
+        fe_shr1(x1);
+    }
+    g = v;
+    r = x2;
+    bool ok = (v.v[0] == 1u);
+#pragma unroll
+    for (int i = 1; i < NL; i++) ok = ok && (v.v[i] == 0);
+    return ok;
+}
+
+// Montgomery form of the inverse of a Montgomery-form value: a = x R  ->  x^-1 R.
+// On failure r = 0 and *fail receives gcd(x R mod N, N) = gcd(x, N) (first failure wins).
+template <int NL>
+__device__ __forceinline__ void fe_inv_mont(Fe<NL> &r, const Fe<NL> &a, const S2Const<NL> &k, uint32_t *__restrict__ fail,
+                                            size_t stride, size_t idx)
+{
+    Fe<NL> c, t, g;
+    fe_canonical_mont(c, a, k.one, k.m);          // canonical x R
+    bool ok = fe_invert(t, g, c, k.m, k.inv_iters);   // (x R)^-1
+    fe_mul(r, t, k.r3, k.m);                      // (xR)^-1 R^3 / R = x^-1 R
+    if (!ok) {
+#pragma unroll
+        for (int i = 0; i < NL; i++) r.v[i] = 0;
+        if (fail[idx] == 0) {                     // limb 0 of the record doubles as the flag
+            bool nz = false;
+#pragma unroll
+            for (int i = 0; i < NL; i++) nz = nz || g.v[i] != 0;
+            if (nz) fe_store(fail, stride, idx, g);
+        }
+    }
+}
+
+// Montgomery's trick on n <= S2_BLK points whose X, Z sit in bx, bz (block tables):
+// out[e0 + i] = X_i / Z_i (Montgomery form, lazy-normalised).  bp = scratch for prefix products.
+template <int NL>
+__device__ __forceinline__ void block_normalise(uint32_t *__restrict__ out, size_t e0, const uint32_t *__restrict__ bx,
+                                                const uint32_t *__restrict__ bz, uint32_t *__restrict__ bp, uint32_t n,
+                                                const S2Const<NL> &k, uint32_t *__restrict__ fail, size_t stride, size_t idx)
+{
+    Fe<NL> acc, z, x, t;
+    tb_load(acc, bz, stride, idx, 0);
+    tb_store(bp, stride, idx, 0, acc);
+    for (uint32_t i = 1; i < n; i++) {            // prefix products  (ecm.c:1889-1893)
+        tb_load(z, bz, stride, idx, i);
+        fe_mul(acc, acc, z, k.m);
+        tb_store(bp, stride, idx, i, acc);
+    }
+    Fe<NL> inv;
+    fe_inv_mont(inv, acc, k, fail, stride, idx);  // (prod Z)^-1
+    for (uint32_t i = n - 1; i > 0; i--) {        // suffix walk  (ecm.c:1965-1987)
+        tb_load(t, bp, stride, idx, i - 1);
+        fe_mul(t, t, inv, k.m);                   // Z_i^-1
+        tb_load(z, bz, stride, idx, i);
+        fe_mul(inv, inv, z, k.m);
+        tb_load(x, bx, stride, idx, i);
+        fe_mul(x, x, t, k.m);
+        tb_store(out, stride, idx, e0 + i, x);
+    }
+    tb_load(x, bx, stride, idx, 0);
+    fe_mul(x, x, inv, k.m);
+    tb_store(out, stride, idx, e0, x);
+}
+
+// P <- [c]P, binary ladder (next_pt_vec, ecm.c:886-976); c is wave-uniform.
+template <int NL>
+__device__ __forceinline__ void pt_ladder(Pt<NL> &P, uint64_t c, const Fe<NL> &s4, const ModK<NL> &m)
+{
+    if (c == 1) return;
+    Fe<NL> s1, d1, s2, d2;
+    Pt<NL> p1 = P, p2;
+    pt_sumdiff(s1, d1, P, m);
+    pt_dup(p2, s1, d1, s4, m);
+    if (c == 2) { P = p2; return; }
+    int top = 63 - __builtin_clzll(c);
+    for (int bit = top - 1; bit >= 0; bit--) {
+        uint32_t b = (uint32_t)((c >> bit) & 1);
+        b = __builtin_amdgcn_readfirstlane(b);
+        if (b) { Pt<NL> t = p1; p1 = p2; p2 = t; }     // so that p2 is always the one added-to
+        // now: add into p2 <- p1 + p2 (diff P), double p1   [bit 0]; with the swap this is the
+        // reference's "add x1, duplicate x2" for bit 1 (ecm.c:945-960)
+        pt_sumdiff(s2, d2, p2, m);
+        pt_sumdiff(s1, d1, p1, m);
+        Fe<NL> pp, mm;
+        pt_add_uv(pp, mm, s1, d1, s2, d2, m);
+        Pt<NL> T, D;
+        fe_mul(T.X, pp, P.Z, m);
+        fe_mul(T.Z, mm, P.X, m);
+        pt_dup(D, s1, d1, s4, m);
+        p2 = T;
+        p1 = D;
+        if (b) { Pt<NL> t = p1; p1 = p2; p2 = t; }
+    }
+    P = p1;
+}
+
+struct S2InitArgs {
+    const uint32_t *X, *Z, *S;       // Q = P after stage 1 (Montgomery form), s = (A+2)/4
+    uint32_t *PbX;                   // out: normalised baby steps, entries 0..npb-1 (0 unused)
+    uint32_t *bx, *bz, *bp;          // block scratch, S2_BLK entries each
+    uint32_t *PdX, *PdZ;             // out: Pd = [D]Q
+    uint32_t *acc;                   // out: accumulator = one
+    uint32_t *fail;                  // per-curve gcd record of a failed inversion (zeroed by host)
+    const uint32_t *keep;            // bitmap over j: bit j set iff map[j] > 0
+    uint32_t umax, D;
+    size_t stride;
+};
+
+// ecm_stage2_init, ecm.c:2201-2340
+template <int NL>
+__device__ __forceinline__ void s2_init(const S2InitArgs &a, const S2Const<NL> &k, size_t idx)
+{
+    const ModK<NL> &m = k.m;
+    const size_t stride = a.stride;
+    Pt<NL> Q, P1, P3;
+    Fe<NL> s4, sQ, dQ;
+    fe_load(Q.X, a.X, stride, idx);
+    fe_load(Q.Z, a.Z, stride, idx);
+    fe_load(s4, a.S, stride, idx);
+    pt_sumdiff(sQ, dQ, Q, m);
+    pt_dup(P1, sQ, dQ, s4, m);                 // [2]Q     ecm.c:2243-2244
+    P3 = Q;
+    // entries 1 and 2
+    tb_store(a.bx, stride, idx, 0, Q.X);  tb_store(a.bz, stride, idx, 0, Q.Z);
+    tb_store(a.bx, stride, idx, 1, P1.X); tb_store(a.bz, stride, idx, 1, P1.Z);
+    uint32_t nblk = 2, e0 = 1;
+    for (uint32_t j = 3; j <= a.umax; j++) {    // ecm.c:2263-2313
+        Fe<NL> s1, d1, pp, mm;
+        pt_sumdiff(s1, d1, P1, m);
+        pt_add_uv(pp, mm, s1, d1, sQ, dQ, m);
+        Pt<NL> T;
+        fe_mul(T.X, pp, P3.Z, m);
+        fe_mul(T.Z, mm, P3.X, m);
+        uint32_t kb = (a.keep[j >> 5] >> (j & 31)) & 1u;
+        kb = __builtin_amdgcn_readfirstlane(kb);
+        if (kb) {
+            tb_store(a.bx, stride, idx, nblk, T.X);
+            tb_store(a.bz, stride, idx, nblk, T.Z);
+            nblk++;
+            if (nblk == S2_BLK) {
+                block_normalise<NL>(a.PbX, e0, a.bx, a.bz, a.bp, nblk, k, a.fail, stride, idx);
+                e0 += nblk;
+                nblk = 0;
+            }
+        }
+        P3 = P1;
+        P1 = T;
+    }
+    if (nblk) block_normalise<NL>(a.PbX, e0, a.bx, a.bz, a.bp, nblk, k, a.fail, stride, idx);
+    Pt<NL> Pd = Q;
+    pt_ladder(Pd, (uint64_t)a.D, s4, m);        // Pd = [w]Q   ecm.c:2332-2334
+    Fe<NL> c;
+    fe_canonical_mont(c, Pd.X, k.one, m); fe_store(a.PdX, stride, idx, c);
+    fe_canonical_mont(c, Pd.Z, k.one, m); fe_store(a.PdZ, stride, idx, c);
+    fe_store(a.acc, stride, idx, k.one);        // acc = one   ecm.c:2318
+}
+
+struct S2PairArgs {
+    const uint32_t *X, *Z, *S;       // Q, s
+    const uint32_t *PbX;             // normalised baby steps
+    const uint32_t *PdX, *PdZ;       // Pd = [D]Q
+    uint32_t *PaX, *PaZ, *PaI;       // giant-step ring, 2L entries each: X, Z, X/Z
+    uint32_t *bp;                    // scratch for prefix products, 2L entries
+    uint32_t *acc;                   // in/out accumulator
+    uint32_t *fail;
+    const uint32_t *steps;           // pair tape: (pa << 16 | 0xffff-marked) see host; 2 words per step
+    uint32_t nsteps, U, L, D;
+    uint64_t A0;                     // 2*amin*D   ecm.c:2378
+    size_t stride;
+};
+
+#define S2_STEP_SHIFT 0xffffffffu
+
+// normalise ring slots [first, first+n) (window positions): PaI = PaX / PaZ
+template <int NL>
+__device__ __forceinline__ void ring_normalise(const S2PairArgs &a, uint32_t w0, uint32_t first, uint32_t n,
+                                               const S2Const<NL> &k, size_t idx)
+{
+    const size_t stride = a.stride;
+    const uint32_t ring = 2 * a.L;
+    Fe<NL> acc, z, x, t;
+    tb_load(acc, a.PaZ, stride, idx, (w0 + first) % ring);
+    tb_store(a.bp, stride, idx, 0, acc);
+    for (uint32_t i = 1; i < n; i++) {
+        tb_load(z, a.PaZ, stride, idx, (w0 + first + i) % ring);
+        fe_mul(acc, acc, z, k.m);
+        tb_store(a.bp, stride, idx, i, acc);
+    }
+    Fe<NL> inv;
+    fe_inv_mont(inv, acc, k, a.fail, stride, idx);
+    for (uint32_t i = n - 1; i > 0; i--) {
+        uint32_t slot = (w0 + first + i) % ring;
+        tb_load(t, a.bp, stride, idx, i - 1);
+        fe_mul(t, t, inv, k.m);
+        tb_load(z, a.PaZ, stride, idx, slot);
+        fe_mul(inv, inv, z, k.m);
+        tb_load(x, a.PaX, stride, idx, slot);
+        fe_mul(x, x, t, k.m);
+        tb_store(a.PaI, stride, idx, slot, x);
+    }
+    uint32_t slot = (w0 + first) % ring;
+    tb_load(x, a.PaX, stride, idx, slot);
+    fe_mul(x, x, inv, k.m);
+    tb_store(a.PaI, stride, idx, slot, x);
+}
+
+// Pa[pos] = Pa[pos-1] + Pd, difference Pa[pos-2]   (ecm.c:2412-2416, 2473-2476)
+template <int NL>
+__device__ __forceinline__ void ring_step(const S2PairArgs &a, uint32_t w0, uint32_t pos, const Fe<NL> &sD, const Fe<NL> &dD,
+                                          const ModK<NL> &m, size_t idx)
+{
+    const size_t stride = a.stride;
+    const uint32_t ring = 2 * a.L;
+    Pt<NL> p1, p2, T;
+    Fe<NL> s1, d1, pp, mm;
+    uint32_t s_1 = (w0 + pos + ring - 1) % ring, s_2 = (w0 + pos + ring - 2) % ring, s_0 = (w0 + pos) % ring;
+    tb_load(p1.X, a.PaX, stride, idx, s_1);
+    tb_load(p1.Z, a.PaZ, stride, idx, s_1);
+    pt_sumdiff(s1, d1, p1, m);
+    pt_add_uv(pp, mm, s1, d1, sD, dD, m);
+    tb_load(p2.X, a.PaX, stride, idx, s_2);
+    tb_load(p2.Z, a.PaZ, stride, idx, s_2);
+    fe_mul(T.X, pp, p2.Z, m);
+    fe_mul(T.Z, mm, p2.X, m);
+    tb_store(a.PaX, stride, idx, s_0, T.X);
+    tb_store(a.PaZ, stride, idx, s_0, T.Z);
+}
+
+// ecm_stage2_pair, ecm.c:2342-2540
+template <int NL>
+__device__ __forceinline__ void s2_pair(const S2PairArgs &a, const S2Const<NL> &k, size_t idx)
+{
+    const ModK<NL> &m = k.m;
+    const size_t stride = a.stride;
+    const uint32_t ring = 2 * a.L;
+    Pt<NL> Q, Pd;
+    Fe<NL> s4, sD, dD;
+    fe_load(Q.X, a.X, stride, idx);
+    fe_load(Q.Z, a.Z, stride, idx);
+    fe_load(s4, a.S, stride, idx);
+    fe_load(Pd.X, a.PdX, stride, idx);
+    fe_load(Pd.Z, a.PdZ, stride, idx);
+    pt_sumdiff(sD, dD, Pd, m);
+    {
+        Pt<NL> P0 = Q, Pad = Q, T;
+        pt_ladder(P0, a.A0, s4, m);                   // Pa[0] = [A]Q      ecm.c:2380-2383
+        pt_ladder(Pad, a.A0 - a.D, s4, m);            // Pad = [A-D]Q     ecm.c:2388-2390
+        Fe<NL> s1, d1, pp, mm;
+        pt_sumdiff(s1, d1, P0, m);
+        pt_add_uv(pp, mm, s1, d1, sD, dD, m);
+        fe_mul(T.X, pp, Pad.Z, m);                    // Pa[1] = Pa[0] + Pd (Pad)   ecm.c:2395-2401
+        fe_mul(T.Z, mm, Pad.X, m);
+        tb_store(a.PaX, stride, idx, 0, P0.X); tb_store(a.PaZ, stride, idx, 0, P0.Z);
+        tb_store(a.PaX, stride, idx, 1, T.X);  tb_store(a.PaZ, stride, idx, 1, T.Z);
+    }
+    uint32_t w0 = 0;
+    for (uint32_t i = 2; i < ring; i++) ring_step<NL>(a, w0, i, sD, dD, m, idx);   // ecm.c:2408-2424
+    ring_normalise<NL>(a, w0, 0, ring, k, idx);                                      // ecm.c:2428
+    Fe<NL> acc;
+    fe_load(acc, a.acc, stride, idx);
+    for (uint32_t sidx = 0; sidx < a.nsteps; sidx++) {
+        uint32_t pa = a.steps[2 * sidx], pb = a.steps[2 * sidx + 1];
+        pa = __builtin_amdgcn_readfirstlane(pa);
+        pb = __builtin_amdgcn_readfirstlane(pb);
+        if (pa == S2_STEP_SHIFT) {                    // window shift by 2U  ecm.c:2458-2502
+            uint32_t sh = 2 * a.U;
+            w0 = (w0 + sh) % ring;
+            for (uint32_t i = ring - sh; i < ring; i++) ring_step<NL>(a, w0, i, sD, dD, m, idx);
+            ring_normalise<NL>(a, w0, ring - sh, sh, k, idx);
+        } else {                                      // CROSS_PRODUCT_INV  ecm.c:1857-1859
+            Fe<NL> x, y, t;
+            tb_load(x, a.PaI, stride, idx, (w0 + pa) % ring);
+            tb_load(y, a.PbX, stride, idx, pb);
+            fe_sub(t, x, y, m);
+            fe_mul(acc, acc, t, m);
+        }
+    }
+    Fe<NL> c;
+    fe_canonical_mont(c, acc, k.one, m);
+    fe_store(a.acc, stride, idx, c);
+}

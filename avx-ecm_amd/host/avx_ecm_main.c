@@ -1,0 +1,254 @@
+/* avx_ecm_main.c — the avx-ecm command line on top of libgecm.
+ *
+ *     avx-ecm input curves B1 [gpus] [B2] [sigma]
+ *
+ * Same positional arguments as the reference (main.c:380-384, 459-460, 537-559); the 4th argument,
+ * "threads" there, is the number of GPUs here (the thread pool is replaced by one host thread per
+ * GPU, each owning one gecm_ctx).  Reproduces vececm's sequence (ecm.c:1077-1544) and its
+ * observable protocol: the banner lines, "Stage 1 completed at prime ..." counters, the factor
+ * lines on stdout and in ecm_results.txt (ecm.c:1356-1367, 1510-1522) and the GMP-ECM resume
+ * lines appended to save_b1.txt (ecm.c:1372-1380), in global curve order (sigma ascending), so the
+ * file is the same for any number of GPUs.  GMP-ECM then resumes with
+ *     ecm -resume save_b1.txt <B1> <B2>
+ * Defaults as the reference: B2 = 100*B1 (main.c:462), B2 <= B1 disables stage 2
+ * (main.c:548-552), sigma = 0 draws random 64-bit sigmas >= 6 (ecm.c:1564-1570).
+ * Curves are processed in batches; the run stops after the batch in which a factor is found
+ * (ecm.c:1531-1532).
+ */
+#include "../../include/gecm.h"
+#include "calc_lite.h"
+#include "gecm_pair.h"
+#include "mpl.h"
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/time.h>
+#include <unistd.h>
+
+#define MAX_GPUS 16
+/* curves per GPU per pass: 2 wavefronts on each of the 1024 SIMDs of an MI355X */
+#define FULL_BATCH 131072u
+
+static double now(void)
+{
+    struct timeval tv;
+    gettimeofday(&tv, NULL);
+    return (double)tv.tv_sec + 1e-6 * (double)tv.tv_usec;
+}
+
+/* lcg_rand, main.c:993-998 */
+static uint64_t lcg_rand(uint64_t *state)
+{
+    *state = 6364136223846793005ULL * (*state) + 1442695040888963407ULL;
+    return *state;
+}
+
+typedef struct {
+    int gpu;
+    gecm_ctx *ctx;
+    uint64_t *sigma;
+    size_t ncurves, first;     /* this GPU's slice of the batch: global indices first .. first+ncurves */
+    uint64_t B1, B2;
+    int do_stage2;
+    int rc;
+    char err[512];
+    double t_build, t_stage1, t_s2;
+} job_t;
+
+static void *job_build(void *p)
+{
+    job_t *j = (job_t *)p;
+    double t = now();
+    j->rc = j->ncurves ? gecm_build_curves(j->ctx, j->sigma, j->ncurves) : 0;
+    if (j->rc < 0) snprintf(j->err, sizeof j->err, "%s", gecm_last_error());
+    j->t_build = now() - t;
+    return NULL;
+}
+
+static void *job_stage1(void *p)
+{
+    job_t *j = (job_t *)p;
+    double t = now();
+    j->rc = 0;
+    if (j->ncurves) {
+        j->rc = gecm_stage1(j->ctx, j->B1);
+        if (j->rc == 0) j->rc = gecm_sync(j->ctx);
+        if (j->rc < 0) snprintf(j->err, sizeof j->err, "%s", gecm_last_error());
+    }
+    j->t_stage1 = now() - t;
+    return NULL;
+}
+
+static void *job_stage2(void *p)
+{
+    job_t *j = (job_t *)p;
+    double t = now();
+    j->rc = 0;
+    if (j->ncurves) {
+        j->rc = gecm_stage2(j->ctx, j->B2, 0, 0);
+        if (j->rc < 0) snprintf(j->err, sizeof j->err, "%s", gecm_last_error());
+    }
+    j->t_s2 = now() - t;
+    return NULL;
+}
+
+static int run_all(job_t *jobs, int n, void *(*fn)(void *))
+{
+    pthread_t th[MAX_GPUS];
+    for (int i = 1; i < n; i++) pthread_create(&th[i], NULL, fn, &jobs[i]);
+    fn(&jobs[0]);
+    for (int i = 1; i < n; i++) pthread_join(th[i], NULL);
+    for (int i = 0; i < n; i++)
+        if (jobs[i].rc < 0) {
+            fprintf(stderr, "GPU %d: %s\n", jobs[i].gpu, jobs[i].err);
+            return -1;
+        }
+    return 0;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 4) {
+        printf("usage: avx-ecm $input $numcurves $B1 [$gpus] [$B2] [$sigma]\n");   /* main.c:382 */
+        return 1;
+    }
+    double t_start = now();
+    printf("starting process %d\n", (int)getpid());                               /* main.c:391 */
+    mpl_t N;
+    if (calc_lite(&N, argv[1]) || mpl_cmp_u64(&N, 3) < 0 || !mpl_is_odd(&N)) {
+        printf("input must evaluate to an odd integer >= 3 (operators + - * / %% ^ ! # fib() luc())\n");
+        return 1;
+    }
+    static char ndec[MPL_MAXL * 10 + 16];
+    mpl_get_dec(ndec, &N);
+    size_t numcurves = strtoul(argv[2], NULL, 10);
+    uint64_t B1 = strtoull(argv[3], NULL, 10);
+    uint64_t B2 = 100ULL * B1;                                                    /* main.c:462 */
+    int gpus = 1, do_stage2 = 1;
+    uint64_t sigma0 = 0;
+    if (argc > 4) gpus = atoi(argv[4]);
+    if (argc > 5) B2 = strtoull(argv[5], NULL, 10);
+    if (argc > 6) sigma0 = strtoull(argv[6], NULL, 10);
+    if (B2 <= B1) do_stage2 = 0;                                                  /* main.c:548-552 */
+    int have = gecm_device_count();
+    if (have < 1) { fprintf(stderr, "no HIP device visible\n"); return 2; }
+    if (gpus < 1) gpus = 1;
+    if (gpus > have) gpus = have;
+    if (gpus > MAX_GPUS) gpus = MAX_GPUS;
+    if (numcurves == 0 || B1 < 2 || B1 > 100000000ULL) { printf("need curves >= 1 and 2 <= B1 <= 1e8\n"); return 1; }
+
+    printf("commencing parallel ecm on %s\n", ndec);                              /* main.c:503 */
+    job_t jobs[MAX_GPUS];
+    memset(jobs, 0, sizeof jobs);
+    for (int g = 0; g < gpus; g++) {
+        jobs[g].gpu = g;
+        if (gecm_create(&jobs[g].ctx, g, ndec, 52)) { fprintf(stderr, "%s\n", gecm_last_error()); return 2; }
+    }
+    gecm_config cfg;
+    gecm_get_config(jobs[0].ctx, &cfg);
+    char devname[256];
+    gecm_device_name(jobs[0].ctx, devname, sizeof devname);
+    /* main.c:529-533; the GPU limb layout replaces VECLEN */
+    printf("ECM has been configured with DIGITBITS = %d, device limbs = %d x 28 bits, %d GPU(s): %s\n",
+           cfg.digitbits, cfg.dev_limbs, gpus, devname);
+    printf("Choosing MAXBITS = %d, NWORDS = %d, NBLOCKS = %d based on input size %d\n", cfg.maxbits, cfg.nwords,
+           cfg.nwords / 4, cfg.nbits);
+    if (sigma0) printf("starting with sigma = %lu\n", (unsigned long)sigma0);     /* main.c:558 */
+    size_t per_pass = (size_t)FULL_BATCH * (size_t)gpus;
+    printf("Input has %d bits, using %d GPU(s) (%zu curves/pass)\n", cfg.nbits, gpus,
+           numcurves < per_pass ? numcurves : per_pass);                          /* main.c:591-592 */
+    printf("Initialization took %1.4f seconds.\n", now() - t_start);              /* main.c:776 */
+
+    uint64_t lcg = (uint64_t)(t_start * 1e6) * 0x9E3779B97F4A7C15ULL + (uint64_t)getpid();
+    int found = 0;
+    static char line[16384], fac[4096];
+    for (size_t done = 0; done < numcurves && !found; done += per_pass) {
+        size_t batch = numcurves - done < per_pass ? numcurves - done : per_pass;
+        printf("\nCommencing curves %zu-%zu of %zu\n", done, done + batch - 1, numcurves);   /* ecm.c:1201 */
+        /* host-side split: GPU g owns global indices [batch*g/G, batch*(g+1)/G) of this pass */
+        uint64_t *sig = (uint64_t *)malloc(batch * sizeof(uint64_t));
+        for (size_t k = 0; k < batch; k++) {
+            if (sigma0) sig[k] = sigma0 + done + k;                              /* main.c:761, ecm.c:1187 */
+            else do { sig[k] = lcg_rand(&lcg); } while (sig[k] < 6);             /* ecm.c:1564-1570 */
+        }
+        for (int g = 0; g < gpus; g++) {
+            size_t lo = batch * (size_t)g / (size_t)gpus, hi = batch * (size_t)(g + 1) / (size_t)gpus;
+            jobs[g].first = lo;
+            jobs[g].ncurves = hi - lo;
+            jobs[g].sigma = sig + lo;
+            jobs[g].B1 = B1;
+            jobs[g].B2 = B2;
+        }
+        double t = now();
+        if (run_all(jobs, gpus, job_build)) return 2;
+        printf("Building curves took %1.4f seconds.\n", now() - t);              /* ecm.c:1204 */
+        printf("Commencing Stage 1 @ prime 2\n");                                /* ecm.c:1233 */
+        t = now();
+        if (run_all(jobs, gpus, job_stage1)) return 2;
+        gecm_stage1_stats st;
+        gecm_get_stage1_stats(jobs[0].ctx, &st);
+        printf("\nStage 1 completed at prime %lu with %lu point-adds and %lu point-doubles\n",
+               (unsigned long)st.last_prime, (unsigned long)st.ptadds, (unsigned long)st.ptdups);   /* ecm.c:1849 */
+        double t1 = now() - t;
+        printf("Stage 1 took %1.4f seconds\n", t1);                              /* ecm.c:1317 */
+        printf("(%.1f curves/sec; kernel %.1f ms on GPU 0)\n", (double)batch / t1, gecm_last_kernel_ms(jobs[0].ctx));
+        /* save + factor scan in global curve order, ecm.c:1319-1388 */
+        FILE *save = fopen("save_b1.txt", "a");
+        if (!save) printf("could not open save_b1.txt for appending, Stage 1 data will not be saved\n");
+        for (int g = 0; g < gpus; g++)
+            for (size_t k = 0; k < jobs[g].ncurves; k++) {
+                int prp = 0;
+                int r = gecm_stage1_factor(jobs[g].ctx, k, fac, sizeof fac, &prp);
+                if (r == 1) {
+                    size_t curve = done + jobs[g].first + k;
+                    printf("\nfound %s%d factor %s in stage 1 (B1 = %lu): thread %d, vec %zu, sigma %lu\n",
+                           prp ? "PRP" : "C", (int)strlen(fac), fac, (unsigned long)B1, g, k,
+                           (unsigned long)jobs[g].sigma[k]);
+                    FILE *out = fopen("ecm_results.txt", "a");
+                    if (out) {
+                        fprintf(out, "\nfound %s%d factor %s in stage 1 (B1 = %lu): curve %zu, thread %d, vec %zu, sigma %lu\n",
+                                prp ? "PRP" : "C", (int)strlen(fac), fac, (unsigned long)B1, curve, g, k,
+                                (unsigned long)jobs[g].sigma[k]);
+                        fclose(out);
+                    }
+                    found = 1;
+                }
+                if (save && gecm_format_save_line(jobs[g].ctx, k, line, sizeof line) > 0) fputs(line, save);
+            }
+        if (save) fclose(save);
+        fflush(stdout);
+        if (do_stage2) {                                                         /* ecm.c:1394-1528 */
+            t = now();
+            if (run_all(jobs, gpus, job_stage2)) return 2;
+            gecm_stage2_stats s2;
+            gecm_get_stage2_stats(jobs[0].ctx, &s2);
+            printf("\nw = %u, L = %u, U = %u, umax = %u\nlast amin: %u\n", s2.D, s2.L, s2.U, s2.U * s2.D, s2.amin_last);
+            printf("\nStage 2 took %1.4f seconds\n", now() - t);                 /* ecm.c:1481 */
+            printf("performed %lu pt-adds, %lu inversions, and %lu pair-muls in stage 2\n",
+                   (unsigned long)s2.ptadds, (unsigned long)s2.numinv, (unsigned long)s2.paired);   /* ecm.c:1482 */
+            for (int g = 0; g < gpus; g++)
+                for (size_t k = 0; k < jobs[g].ncurves; k++) {
+                    int prp = 0;
+                    if (gecm_stage2_factor(jobs[g].ctx, k, fac, sizeof fac, &prp) == 1) {
+                        size_t curve = done + jobs[g].first + k;
+                        printf("\nfound %s%d factor %s in stage 2 (B2 = %lu): thread %d, vec %zu, sigma %lu\n",
+                               prp ? "PRP" : "C", (int)strlen(fac), fac, (unsigned long)B2, g, k,
+                               (unsigned long)jobs[g].sigma[k]);
+                        FILE *out = fopen("ecm_results.txt", "a");
+                        if (out) {
+                            fprintf(out, "\nfound %s%d factor %s in stage 2 (B2 = %lu): curve %zu, thread %d, vec %zu, sigma %lu\n",
+                                    prp ? "PRP" : "C", (int)strlen(fac), fac, (unsigned long)B2, curve, g, k,
+                                    (unsigned long)jobs[g].sigma[k]);
+                            fclose(out);
+                        }
+                        found = 1;
+                    }
+                }
+        }
+        free(sig);
+    }
+    for (int g = 0; g < gpus; g++) gecm_destroy(jobs[g].ctx);
+    printf("Process took %1.4f seconds.\n", now() - t_start);                    /* ecm.c:1538 */
+    return 0;
+}

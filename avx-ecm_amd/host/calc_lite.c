@@ -1,0 +1,180 @@
+/* calc_lite.c — input-expression evaluator for the avx-ecm command line.
+ *
+ * The reference accepts its first argument as an expression (calc.c:683-1104, README.md:30), e.g.
+ * "fib(791)/13/677/216416017".  This is a small recursive-descent evaluator over the mpl integers
+ * covering the operators a factoring command line uses:
+ *     + - * / % ^      binary, usual precedence, ^ right-associative, / exact or truncating
+ *     n!  n#           factorial and primorial (postfix)
+ *     fib(n) luc(n)    Fibonacci and Lucas numbers
+ *     ( )              grouping; decimal or 0x-hex literals
+ * Values are non-negative and bounded by the mpl capacity (4352 bits); a subtraction that would go
+ * negative or an overflow is an error (return code != 0), never a wrong number.
+ */
+#include "calc_lite.h"
+#include <ctype.h>
+#include <string.h>
+
+typedef struct {
+    const char *s;
+    int err;
+} P;
+
+static void skip(P *p) { while (*p->s == ' ' || *p->s == '\t') p->s++; }
+static void expr(P *p, mpl_t *r);
+
+static int fits(const mpl_t *a, const mpl_t *b) { return a->n + b->n <= MPL_MAXL - 2; }
+
+static void fibluc(P *p, mpl_t *r, uint64_t n, int lucas)
+{
+    mpl_t a, b, t;
+    mpl_set_u64(&a, lucas ? 2 : 0);
+    mpl_set_u64(&b, 1);
+    for (uint64_t i = 0; i < n; i++) {
+        if (b.n >= MPL_MAXL - 2) { p->err = 1; return; }
+        mpl_add(&t, &a, &b);
+        a = b;
+        b = t;
+    }
+    *r = a;
+}
+
+static void primary(P *p, mpl_t *r)
+{
+    skip(p);
+    if (p->err) return;
+    if (*p->s == '(') {
+        p->s++;
+        expr(p, r);
+        skip(p);
+        if (*p->s != ')') { p->err = 1; return; }
+        p->s++;
+    } else if (isalpha((unsigned char)*p->s)) {
+        char name[8];
+        int k = 0;
+        while (isalpha((unsigned char)*p->s) && k < 7) name[k++] = (char)tolower((unsigned char)*p->s++);
+        name[k] = 0;
+        skip(p);
+        if (*p->s != '(') { p->err = 1; return; }
+        p->s++;
+        mpl_t arg;
+        expr(p, &arg);
+        skip(p);
+        if (p->err || *p->s != ')') { p->err = 1; return; }
+        p->s++;
+        if (arg.n > 1 || mpl_get_u64(&arg) > 100000) { p->err = 1; return; }
+        if (!strcmp(name, "fib")) fibluc(p, r, mpl_get_u64(&arg), 0);
+        else if (!strcmp(name, "luc")) fibluc(p, r, mpl_get_u64(&arg), 1);
+        else p->err = 1;
+    } else if (isdigit((unsigned char)*p->s)) {
+        char buf[2048];
+        int k = 0;
+        if (p->s[0] == '0' && (p->s[1] == 'x' || p->s[1] == 'X')) {
+            buf[k++] = *p->s++;
+            buf[k++] = *p->s++;
+            while (isxdigit((unsigned char)*p->s) && k < 2040) buf[k++] = *p->s++;
+        } else {
+            while (isdigit((unsigned char)*p->s) && k < 2040) buf[k++] = *p->s++;
+        }
+        buf[k] = 0;
+        if (mpl_set_str(r, buf)) p->err = 1;
+    } else {
+        p->err = 1;
+    }
+    /* postfix ! and # */
+    for (;;) {
+        skip(p);
+        if (p->err) return;
+        if (*p->s == '!' || *p->s == '#') {
+            int prim = *p->s == '#';
+            p->s++;
+            if (r->n > 1 || mpl_get_u64(r) > 100000) { p->err = 1; return; }
+            uint64_t n = mpl_get_u64(r);
+            mpl_t acc;
+            mpl_set_u64(&acc, 1);
+            for (uint64_t i = 2; i <= n; i++) {
+                if (prim) {
+                    int isp = 1;
+                    for (uint64_t d = 2; d * d <= i; d++)
+                        if (i % d == 0) { isp = 0; break; }
+                    if (!isp) continue;
+                }
+                if (acc.n >= MPL_MAXL - 3) { p->err = 1; return; }
+                mpl_mul_u64(&acc, &acc, i);
+            }
+            *r = acc;
+        } else {
+            return;
+        }
+    }
+}
+
+static void power(P *p, mpl_t *r)
+{
+    primary(p, r);
+    skip(p);
+    if (!p->err && *p->s == '^') {
+        p->s++;
+        mpl_t e, base = *r, acc;
+        power(p, &e);                       /* right-associative */
+        if (p->err || e.n > 1 || mpl_get_u64(&e) > 100000) { p->err = 1; return; }
+        uint64_t n = mpl_get_u64(&e);
+        mpl_set_u64(&acc, 1);
+        for (uint64_t i = 0; i < n; i++) {
+            if (!fits(&acc, &base)) { p->err = 1; return; }
+            mpl_mul(&acc, &acc, &base);
+        }
+        *r = acc;
+    }
+}
+
+static void term(P *p, mpl_t *r)
+{
+    power(p, r);
+    for (;;) {
+        skip(p);
+        if (p->err) return;
+        char op = *p->s;
+        if (op != '*' && op != '/' && op != '%') return;
+        p->s++;
+        mpl_t b, q, rem;
+        power(p, &b);
+        if (p->err) return;
+        if (op == '*') {
+            if (!fits(r, &b)) { p->err = 1; return; }
+            mpl_mul(r, r, &b);
+        } else {
+            if (mpl_is_zero(&b)) { p->err = 1; return; }
+            mpl_divrem(&q, &rem, r, &b);
+            *r = op == '/' ? q : rem;
+        }
+    }
+}
+
+static void expr(P *p, mpl_t *r)
+{
+    term(p, r);
+    for (;;) {
+        skip(p);
+        if (p->err) return;
+        char op = *p->s;
+        if (op != '+' && op != '-') return;
+        p->s++;
+        mpl_t b;
+        term(p, &b);
+        if (p->err) return;
+        if (op == '+') mpl_add(r, r, &b);
+        else {
+            if (mpl_cmp(r, &b) < 0) { p->err = 1; return; }
+            mpl_sub(r, r, &b);
+        }
+    }
+}
+
+int calc_lite(mpl_t *out, const char *s)
+{
+    P p = {s, 0};
+    expr(&p, out);
+    skip(&p);
+    if (p.err || *p.s) return -1;
+    return 0;
+}

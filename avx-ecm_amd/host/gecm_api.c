@@ -9,6 +9,7 @@
 #include "../../include/gecm.h"
 #include "../csrc/gecm_dev.h"
 #include "gecm_plan.h"
+#include "gecm_pair.h"
 #include "mpl.h"
 #include <stdarg.h>
 #include <stdio.h>
@@ -52,6 +53,14 @@ struct gecm_ctx {
     uint64_t tape_B1;
     int tape_on_dev;
     double last_ms;
+    /* stage 2 */
+    uint32_t *r3_28;
+    gecm_s2_plan s2;
+    int s2_ready;
+    uint32_t *hacc, *hfail;
+    int have_acc;
+    uint64_t s2_ptadds, s2_numinv, s2_paired, s2_devinv;
+    uint32_t s2_amin_last;
 };
 
 static int pick_nl(int nbits)
@@ -145,14 +154,22 @@ int gecm_create(gecm_ctx **out, int device, const char *n_str, int digitbits)
         free(c);
         return GECM_ERR_DEVICE;
     }
+    /* R^3 mod N for the device inversion (csrc/gecm_stage2.hpp: fe_inv_mont) */
+    c->r3_28 = (uint32_t *)calloc((size_t)nl, sizeof(uint32_t));
+    if (!c->r3_28) { gecm_destroy(c); return GECM_ERR_NOMEM; }
+    mpl_mulmod(&t, &c->rint_mod_n, &c->rint_mod_n, &c->N);
+    mpl_mulmod(&t, &t, &c->rint_mod_n, &c->N);
+    mpl_to_limbs32(c->r3_28, 1, nl, LIMB_BITS, &t);
+    gecm_dev_set_s2const(c->dev, c->r3_28, (uint32_t)(2 * c->nbits + 2));
     *out = c;
     return GECM_OK;
 }
 
 static void free_batch(gecm_ctx *c)
 {
-    free(c->sigma); free(c->bad); free(c->hx); free(c->hz);
-    c->sigma = NULL; c->bad = NULL; c->hx = c->hz = NULL;
+    free(c->sigma); free(c->bad); free(c->hx); free(c->hz); free(c->hacc); free(c->hfail);
+    c->sigma = NULL; c->bad = NULL; c->hx = c->hz = NULL; c->hacc = c->hfail = NULL;
+    c->have_acc = 0; c->s2_ready = 0;
     c->batch = 0;
     c->have_plain = 0;
 }
@@ -164,6 +181,8 @@ void gecm_destroy(gecm_ctx *c)
     gecm_dev_close(c->dev_l0);
     gecm_tape_free(&c->tape);
     free_batch(c);
+    gecm_s2_plan_free(&c->s2);
+    free(c->r3_28);
     free(c->n28);
     free(c);
 }
@@ -275,7 +294,9 @@ static int alloc_batch(gecm_ctx *c, size_t batch)
     c->bad = (uint8_t *)calloc(batch, 1);
     c->hx = (uint32_t *)calloc(batch * (size_t)c->nl, 4);
     c->hz = (uint32_t *)calloc(batch * (size_t)c->nl, 4);
-    if (!c->sigma || !c->bad || !c->hx || !c->hz) { free_batch(c); return GECM_ERR_NOMEM; }
+    c->hacc = (uint32_t *)calloc(batch * (size_t)c->nl, 4);
+    c->hfail = (uint32_t *)calloc(batch * (size_t)c->nl, 4);
+    if (!c->sigma || !c->bad || !c->hx || !c->hz || !c->hacc || !c->hfail) { free_batch(c); return GECM_ERR_NOMEM; }
     c->batch = batch;
     if (gecm_dev_resize(c->dev, batch)) { set_err("%s", gecm_dev_error()); return GECM_ERR_DEVICE; }
     return GECM_OK;
@@ -427,6 +448,8 @@ int gecm_stage1(gecm_ctx *c, uint64_t B1)
     }
     c->B1 = B1;
     c->have_plain = 0;
+    c->have_acc = 0;
+    c->s2_ready = 0;
     if (gecm_dev_stage1(c->dev)) { set_err("%s", gecm_dev_error()); return GECM_ERR_DEVICE; }
     return GECM_OK;
 }
@@ -531,6 +554,169 @@ int gecm_stage1_factor(gecm_ctx *c, size_t k, char *dec, size_t declen, int *is_
             memcpy(dec, tmp, (size_t)n + 1);
         }
         if (is_prp) *is_prp = mpl_probab_prime(&g, 3);   /* ecm.c:1346 */
+        return 1;
+    }
+    return 0;
+}
+
+/* ---- stage 2 -------------------------------------------------------------------------------- */
+/* point additions next_pt_vec performs for multiplier c (one per bit below the top one, ecm.c:939-966) */
+static uint64_t ladder_adds(uint64_t c)
+{
+    uint64_t n = 0;
+    if (c <= 2) return 0;
+    while (c > 1) { n++; c >>= 1; }
+    return n;
+}
+
+int gecm_stage2_init(gecm_ctx *c, uint32_t D, uint32_t U)
+{
+    if (!c || c->batch == 0 || c->B1 == 0) { set_err("gecm_stage2_init: run stage 1 first"); return GECM_ERR_STATE; }
+    if (!D) D = gecm_s2_default_D(c->B1);
+    if (!U) U = GECM_S2_DEFAULT_U;
+    if (c->s2.D != D || c->s2.U != U) {
+        gecm_s2_plan_free(&c->s2);
+        if (gecm_s2_plan_init(&c->s2, D, U)) { set_err("gecm_stage2_init: bad D/U"); return GECM_ERR_ARG; }
+    }
+    c->have_acc = 0;
+    c->s2_ptadds = (uint64_t)c->s2.umax - 2 + ladder_adds(D);   /* ecm.c:2263: j = 3..U*w; Pd ladder :2334 */
+    c->s2_numinv = 1;                                        /* ecm.c:2322 */
+    c->s2_devinv = (c->s2.npb - 1 + 31) / 32;
+    c->s2_paired = 0;
+    if (gecm_dev_s2_init(c->dev, c->s2.keep, c->s2.keep_words, c->s2.umax, D, c->s2.npb, c->s2.L)) {
+        set_err("gecm_stage2_init: %s", gecm_dev_error());
+        return GECM_ERR_DEVICE;
+    }
+    c->s2_ready = 1;
+    return GECM_OK;
+}
+
+int gecm_pair_primes(gecm_pairs *out, uint64_t B1, uint64_t B2, uint32_t D, uint32_t U)
+{
+    gecm_pairmap pm;
+    if (!out || B2 <= B1 || !D || !U) { set_err("gecm_pair_primes: bad argument"); return GECM_ERR_ARG; }
+    if (gecm_pair(&pm, B1, B2, D, U)) { set_err("gecm_pair_primes: out of memory"); return GECM_ERR_NOMEM; }
+    out->pairmap_v = pm.v; out->pairmap_u = pm.u; out->steps = pm.steps; out->amin = pm.amin;
+    out->pairs = pm.pairs; out->primes = pm.nump;
+    return GECM_OK;
+}
+
+void gecm_pairmap_release(gecm_pairs *p)
+{
+    if (!p) return;
+    free(p->pairmap_v);
+    free(p->pairmap_u);
+    memset(p, 0, sizeof *p);
+}
+
+int gecm_stage2_pair(gecm_ctx *c, uint32_t steps, const uint32_t *pm_v, const uint32_t *pm_u, uint32_t amin)
+{
+    if (!c || !c->s2_ready) { set_err("gecm_stage2_pair: gecm_stage2_init has not run"); return GECM_ERR_STATE; }
+    if (steps && (!pm_v || !pm_u)) return GECM_ERR_ARG;
+    const gecm_s2_plan *p = &c->s2;
+    /* resolve the map on the host: window index pa = v - amin (ecm.c:2505), table index map[u] */
+    uint32_t *tape = (uint32_t *)malloc(((size_t)steps * 2 + 2) * sizeof(uint32_t));
+    if (!tape) return GECM_ERR_NOMEM;
+    uint32_t run_amin = amin;
+    uint64_t adds = 2ull * p->L - 1, inv = 2, paired = 0, devinv = 1;   /* ecm.c:2401-2429 */
+    for (uint32_t i = 0; i < steps; i++) {
+        if (pm_v[i] == 0 && pm_u[i] == 0) {
+            tape[2 * i] = 0xffffffffu;
+            tape[2 * i + 1] = 0;
+            run_amin += p->U;                                            /* ecm.c:2496 */
+            adds += 2ull * p->U; inv++; devinv++;
+        } else {
+            uint32_t pa = pm_v[i] - run_amin, pb = pm_u[i];
+            if (pa >= 2 * p->L || pb > p->umax || p->map[pb] == 0) {     /* ecm.c:2508-2517 */
+                free(tape);
+                set_err("gecm_stage2_pair: invalid pair map entry %u: (%u,%u) amin %u", i, pm_v[i], pm_u[i], run_amin);
+                return GECM_ERR_ARG;
+            }
+            tape[2 * i] = pa;
+            tape[2 * i + 1] = p->map[pb];
+            paired++;
+        }
+    }
+    uint64_t A0 = (uint64_t)amin * p->D * 2;                             /* ecm.c:2378 */
+    adds += ladder_adds(A0) + ladder_adds(A0 - p->D);                    /* ecm.c:2383, 2390 */
+    int rc = gecm_dev_s2_pair(c->dev, tape, steps, p->U, p->L, p->D, A0);
+    free(tape);
+    if (rc) { set_err("gecm_stage2_pair: %s", gecm_dev_error()); return GECM_ERR_DEVICE; }
+    c->s2_ptadds += adds; c->s2_numinv += inv; c->s2_paired += paired; c->s2_devinv += devinv;
+    c->s2_amin_last = run_amin;
+    c->have_acc = 0;
+    return GECM_OK;
+}
+
+int gecm_stage2(gecm_ctx *c, uint64_t B2, uint32_t D, uint32_t U)
+{
+    const uint64_t PRIME_RANGE = 100000000ull;                           /* main.c:581 */
+    if (!c || c->B1 == 0 || B2 <= c->B1) { set_err("gecm_stage2: need B2 > B1 and a finished stage 1"); return GECM_ERR_ARG; }
+    int rc = gecm_stage2_init(c, D, U);
+    if (rc) return rc;
+    for (uint64_t p = c->B1; p < B2; p += PRIME_RANGE) {                 /* ecm.c:1424-1476 */
+        uint64_t hi = p + PRIME_RANGE < B2 ? p + PRIME_RANGE : B2;
+        gecm_pairs pm;
+        rc = gecm_pair_primes(&pm, p, hi, c->s2.D, c->s2.U);
+        if (rc) return rc;
+        rc = gecm_stage2_pair(c, pm.steps, pm.pairmap_v, pm.pairmap_u, pm.amin);
+        gecm_pairmap_release(&pm);
+        if (rc) return rc;
+    }
+    return gecm_sync(c);
+}
+
+int gecm_get_stage2_stats(const gecm_ctx *c, gecm_stage2_stats *st)
+{
+    if (!c || !st || !c->s2.D) return GECM_ERR_STATE;
+    st->ptadds = c->s2_ptadds; st->numinv = c->s2_numinv; st->paired = c->s2_paired;
+    st->device_inversions = c->s2_devinv;
+    st->D = c->s2.D; st->U = c->s2.U; st->L = c->s2.L; st->amin_last = c->s2_amin_last;
+    return GECM_OK;
+}
+
+static int fetch_acc(gecm_ctx *c)
+{
+    if (c->have_acc) return GECM_OK;
+    if (!c->s2_ready) { set_err("no stage-2 state"); return GECM_ERR_STATE; }
+    if (gecm_dev_s2_download(c->dev, c->hacc, c->hfail)) { set_err("%s", gecm_dev_error()); return GECM_ERR_DEVICE; }
+    c->have_acc = 1;
+    return GECM_OK;
+}
+
+int gecm_download_acc(gecm_ctx *c, void *acc)
+{
+    if (!c || !acc) return GECM_ERR_ARG;
+    int rc = fetch_acc(c);
+    if (rc) return rc;
+    for (size_t i = 0; i < c->batch; i++) {
+        mpl_t v;
+        mpl_from_limbs32(&v, c->hacc + i, c->batch, c->nl, LIMB_BITS);
+        mpl_mulmod(&v, &v, &c->int_to_ref, &c->N);
+        vec_put(c, acc, c->batch, i, &v);
+    }
+    return GECM_OK;
+}
+
+int gecm_stage2_factor(gecm_ctx *c, size_t k, char *dec, size_t declen, int *is_prp)
+{
+    if (!c || k >= c->batch) return GECM_ERR_ARG;
+    int rc = fetch_acc(c);
+    if (rc) return rc;
+    mpl_t a, g;
+    mpl_from_limbs32(&g, c->hfail + k, c->batch, c->nl, LIMB_BITS);
+    if (mpl_is_zero(&g)) {
+        mpl_from_limbs32(&a, c->hacc + k, c->batch, c->nl, LIMB_BITS);
+        mpl_gcd(&g, &a, &c->N);                      /* check_factor, ecm.c:2542-2557 */
+    }
+    if (mpl_cmp_u64(&g, 1) > 0 && mpl_cmp(&g, &c->N) != 0) {
+        static __thread char tmp[MPL_MAXL * 10 + 16];
+        int n = mpl_get_dec(tmp, &g);
+        if (dec && declen) {
+            if ((size_t)n >= declen) { set_err("gecm_stage2_factor: buffer too small"); return GECM_ERR_ARG; }
+            memcpy(dec, tmp, (size_t)n + 1);
+        }
+        if (is_prp) *is_prp = mpl_probab_prime(&g, 3);
         return 1;
     }
     return 0;

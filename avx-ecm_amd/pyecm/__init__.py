@@ -66,6 +66,30 @@ _sig("gecm_format_save_line", c_int, c_void_p, c_size_t, c_char_p, c_size_t)
 _sig("gecm_stage1_factor", c_int, c_void_p, c_size_t, c_char_p, c_size_t, ctypes.POINTER(c_int))
 
 
+class Stage2Stats(ctypes.Structure):
+    _fields_ = [("ptadds", c_u64), ("numinv", c_u64), ("paired", c_u64), ("device_inversions", c_u64),
+                ("D", ctypes.c_uint32), ("U", ctypes.c_uint32), ("L", ctypes.c_uint32), ("amin_last", ctypes.c_uint32)]
+
+
+class Pairs(ctypes.Structure):
+    _fields_ = [("pairmap_v", ctypes.POINTER(ctypes.c_uint32)), ("pairmap_u", ctypes.POINTER(ctypes.c_uint32)),
+                ("steps", ctypes.c_uint32), ("amin", ctypes.c_uint32), ("pairs", ctypes.c_uint32),
+                ("primes", ctypes.c_uint32)]
+
+
+_sig("gecm_stage2_init", c_int, c_void_p, ctypes.c_uint32, ctypes.c_uint32)
+_sig("gecm_pair_primes", c_int, ctypes.POINTER(Pairs), c_u64, c_u64, ctypes.c_uint32, ctypes.c_uint32)
+_sig("gecm_pairmap_release", None, ctypes.POINTER(Pairs))
+_sig("gecm_stage2_pair", c_int, c_void_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32),
+     ctypes.POINTER(ctypes.c_uint32), ctypes.c_uint32)
+_sig("gecm_stage2", c_int, c_void_p, c_u64, ctypes.c_uint32, ctypes.c_uint32)
+_sig("gecm_get_stage2_stats", c_int, c_void_p, ctypes.POINTER(Stage2Stats))
+_sig("gecm_download_acc", c_int, c_void_p, c_void_p)
+_sig("gecm_stage2_factor", c_int, c_void_p, c_size_t, c_char_p, c_size_t, ctypes.POINTER(c_int))
+EXPORTS += ["gecm_stage2_init", "gecm_pair_primes", "gecm_pairmap_release", "gecm_stage2_pair", "gecm_stage2",
+            "gecm_get_stage2_stats", "gecm_download_acc", "gecm_stage2_factor"]
+
+
 class GecmError(RuntimeError):
     pass
 
@@ -74,6 +98,12 @@ def _chk(rc, what):
     if rc < 0:
         raise GecmError("%s failed (%d): %s" % (what, rc, lib.gecm_last_error().decode()))
     return rc
+
+
+def pair_primes(b1, b2, D, U):
+    p = Pairs()
+    _chk(lib.gecm_pair_primes(ctypes.byref(p), b1, b2, D, U), "gecm_pair_primes")
+    return p
 
 
 def device_count():
@@ -201,6 +231,36 @@ class Engine:
         buf = ctypes.create_string_buffer(2048)
         prp = c_int(0)
         rc = _chk(lib.gecm_stage1_factor(self._h, k, buf, len(buf), ctypes.byref(prp)), "gecm_stage1_factor")
+        return (int(buf.value.decode()), bool(prp.value)) if rc == 1 else None
+
+    # ---- stage 2 ----
+    def stage2(self, b2, D=0, U=0):
+        _chk(lib.gecm_stage2(self._h, b2, D, U), "gecm_stage2")
+
+    def stage2_init(self, D=0, U=0, sync=True):
+        _chk(lib.gecm_stage2_init(self._h, D, U), "gecm_stage2_init")
+        if sync:
+            self.sync()
+
+    def stage2_pair(self, pairs, sync=True):
+        _chk(lib.gecm_stage2_pair(self._h, pairs.steps, pairs.pairmap_v, pairs.pairmap_u, pairs.amin), "gecm_stage2_pair")
+        if sync:
+            self.sync()
+
+    def stage2_stats(self):
+        st = Stage2Stats()
+        _chk(lib.gecm_get_stage2_stats(self._h, ctypes.byref(st)), "gecm_get_stage2_stats")
+        return st
+
+    def download_acc(self):
+        A = self.empty(self.batch)
+        _chk(lib.gecm_download_acc(self._h, A), "gecm_download_acc")
+        return self.unpack(A, self.batch)
+
+    def stage2_factor(self, k):
+        buf = ctypes.create_string_buffer(2048)
+        prp = c_int(0)
+        rc = _chk(lib.gecm_stage2_factor(self._h, k, buf, len(buf), ctypes.byref(prp)), "gecm_stage2_factor")
         return (int(buf.value.decode()), bool(prp.value)) if rc == 1 else None
 
     def device_name(self):

@@ -117,6 +117,53 @@ int gecm_format_save_line(gecm_ctx *ctx, size_t k, char *buf, size_t buflen);
  * 1 < g < N, else 0 (g == N is "no factor", ecm.c:2549-2553).                                 */
 int gecm_stage1_factor(gecm_ctx *ctx, size_t k, char *dec, size_t declen, int *is_prp);
 
+/* ---- L1 phase 2: stage-2 init (ecm_stage2_init, ecm.c:2201-2340) --------------------------
+ * Q = the stage-1 result resident on the device.  Builds the baby-step table Pb[map[j]] = [j]Q for
+ * j <= U*D with gcd(j, D) = 1 (X/Z-normalised by batch inversion, ecm.c:2322), Pd = [D]Q and
+ * acc = one.  D = 0 picks the reference's wheel for the current B1 (main.c:838-872); U = 0 picks 16
+ * (the value every reference run chose through its uninitialised `paircost`, main.c:912, 943).
+ * Asynchronous; gecm_sync waits.                                                                */
+int gecm_stage2_init(gecm_ctx *ctx, uint32_t D, uint32_t U);
+
+/* ---- host pair map (pair, ecm.c:2559-2910) --------------------------------------------------
+ * Montgomery's PAIR over the primes in [B1, B2) for wheel D and table height U.  Arrays are
+ * malloc'ed; release with gecm_pairmap_release.  (0,0) entries mean "advance the window".       */
+typedef struct {
+    uint32_t *pairmap_v, *pairmap_u;   /* ecm.c:2559 */
+    uint32_t steps;                    /* return value of pair() */
+    uint32_t amin;                     /* work->amin set at ecm.c:2571 */
+    uint32_t pairs, primes;            /* printed at ecm.c:2904-2905 */
+} gecm_pairs;
+int gecm_pair_primes(gecm_pairs *out, uint64_t B1, uint64_t B2, uint32_t D, uint32_t U);
+void gecm_pairmap_release(gecm_pairs *p);
+
+/* ---- L1 phase 3: stage-2 pair (ecm_stage2_pair, ecm.c:2342-2540) ----------------------------
+ * One B2 range: giant steps from A = 2*amin*D, window of 2L = 4U steps, walk of the pair map,
+ * acc <- acc * (Xa/Za - Xb/Zb) per pair (CROSS_PRODUCT_INV, ecm.c:1857-1859).  Same arguments as the
+ * reference (pairmap_steps, pairmap_v, pairmap_u, work->amin).  Asynchronous.                   */
+int gecm_stage2_pair(gecm_ctx *ctx, uint32_t steps, const uint32_t *pairmap_v, const uint32_t *pairmap_u,
+                     uint32_t amin);
+
+/* Convenience: the whole stage-2 sequence of vececm (ecm.c:1401-1476) for primes in [B1, B2):
+ * init, then pair + stage2_pair per range of 1e8.  Synchronous.                                  */
+int gecm_stage2(gecm_ctx *ctx, uint64_t B2, uint32_t D, uint32_t U);
+
+typedef struct {
+    uint64_t ptadds, numinv, paired;   /* the reference's counters, ecm.c:1482-1483 (numinv as the
+                                          reference counts it; the device normalises the baby-step
+                                          table in blocks, see stage2_device_inversions) */
+    uint64_t device_inversions;
+    uint32_t D, U, L, amin_last;
+} gecm_stage2_stats;
+int gecm_get_stage2_stats(const gecm_ctx *ctx, gecm_stage2_stats *st);
+
+/* stg2acc as a vec operand (reference layout, Montgomery radix, canonical), ecm.c:1489 */
+int gecm_download_acc(gecm_ctx *ctx, void *acc);
+/* Factor check after stage 2 (ecm.c:1485-1528): gcd(acc_k, N), or — when a batch inversion met a
+ * non-invertible product (ecm.c:1927-1939) — the gcd recorded then.  Returns 1 and the decimal
+ * factor if 1 < g < N, else 0.                                                                  */
+int gecm_stage2_factor(gecm_ctx *ctx, size_t k, char *dec, size_t declen, int *is_prp);
+
 #ifdef __cplusplus
 }
 #endif

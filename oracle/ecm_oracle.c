@@ -616,9 +616,13 @@ static void batch_invert(const orc_ctx *c, orc_work *w, const uint64_t *const *Z
     orc_mulmod(c, prefix[num - 1], one, B[num - 1]);          /* out of Montgomery form, :1903-1912 */
     fe_to_mpz(c, g, B[num - 1]);
     if (mpz_invert(inv, g, c->N) == 0) {                      /* :1925-1939 */
-        mpz_gcd(w->inv_factor, g, c->N);
+        /* The reference stores gcd(product, N) into stg2acc and goes on with whatever its
+         * destination variable held (mpz_invert leaves it untouched; insert_mpz_to_vec of 0
+         * writes nothing, main.c:117-138), i.e. lane-order-dependent garbage.  Not restated:
+         * here the first such gcd is recorded and the inverse is taken as 0, which is what the
+         * product (csrc/gecm_stage2.hpp: fe_inv_mont) does too. */
+        if (!w->found_during_inv) mpz_gcd(w->inv_factor, g, c->N);
         w->found_during_inv = 1;
-        fe_from_mpz(c, w->stg2acc, w->inv_factor);
         mpz_set_ui(inv, 0);
     }
     mpz_mul_2exp(inv, inv, (mp_bitcnt_t)c->maxbits);          /* :1944-1945 */
@@ -880,6 +884,10 @@ int orc_stage2(orc_ctx *c, uint64_t sigma, uint64_t B1, uint64_t B2, uint32_t D,
     mpz_t f, t;
     mpz_inits(f, t, NULL);
     int found = orc_check_factor(c, w->stg2acc, f);         /* ecm.c:1489-1490 */
+    if (w->found_during_inv) {
+        mpz_set(f, w->inv_factor);
+        found = mpz_cmp_ui(f, 1) > 0 && mpz_cmp(f, c->N) != 0;
+    }
     if (factor_dec && faclen) {
         factor_dec[0] = 0;
         if (found) gmp_snprintf(factor_dec, faclen, "%Zd", f);

@@ -1,0 +1,176 @@
+"""CPU tests (no GPU): the C-ABI library loads, exports every symbol include/gecm.h declares, fails
+loudly without a device, and its host logic (tape compiler, sieve, PAIR, curve-setup arithmetic)
+agrees with the reference-derived fixtures and with the oracle."""
+import ctypes
+import json
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+LIB = os.path.join(ROOT, "avx-ecm_amd", "libgecm.so")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(LIB):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "avx-ecm_amd"), "-j8"])
+    return ctypes.CDLL(LIB)
+
+
+def test_header_symbols_all_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "gecm.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = set(re.findall(r"\b(gecm_[a-z0-9_]+)\s*\(", hdr))
+    assert len(names) >= 25
+    missing = [n for n in sorted(names) if not hasattr(lib, n)]
+    assert not missing, missing
+    import pyecm
+    assert set(pyecm.EXPORTS) == names
+
+
+def test_no_device_is_a_loud_error_not_a_fallback(lib):
+    import pyecm
+    if pyecm.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(pyecm.GecmError):
+        pyecm.Engine((1 << 127) - 1)
+    # and bad arguments are rejected before the device is touched
+    h = ctypes.c_void_p()
+    lib.gecm_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_char_p, ctypes.c_int]
+    assert lib.gecm_create(ctypes.byref(h), 0, b"1000", 52) == -2      # even N
+    assert lib.gecm_create(ctypes.byref(h), 0, b"1001", 48) == -2      # bad limb format
+
+
+class Tape(ctypes.Structure):
+    _fields_ = [("ops", ctypes.POINTER(ctypes.c_uint8)), ("len", ctypes.c_size_t), ("ptadds", ctypes.c_uint64),
+                ("ptdups", ctypes.c_uint64), ("prac_calls", ctypes.c_uint64), ("last_prime", ctypes.c_uint64),
+                ("rule_count", ctypes.c_uint64 * 4), ("swaps", ctypes.c_uint64)]
+
+
+def test_tape_counts_match_reference_counters(lib):
+    """the reference prints ptadds/ptdups after stage 1 (ecm.c:1849-1850); fixtures hold them"""
+    cases = json.load(open(os.path.join(GOLDEN, "stage1.json")))
+    seen = {}
+    for c in cases:
+        seen[c["B1"]] = (c["ptadds"], c["ptdups"])
+    for b1, (adds, dups) in sorted(seen.items()):
+        t = Tape()
+        assert lib.gecm_tape_build_stage1(ctypes.byref(t), ctypes.c_uint64(b1)) == 0
+        assert (t.ptadds, t.ptdups) == (adds, dups), b1
+        assert t.len == t.prac_calls * 2 + sum(t.rule_count) + sum(1 for k in range(1, 64) if 2 ** k < b1)
+        lib.gecm_tape_free(ctypes.byref(t))
+    # op mix at B1=1e6
+    t = Tape()
+    lib.gecm_tape_build_stage1(ctypes.byref(t), ctypes.c_uint64(1000000))
+    assert t.prac_calls == 78715 and list(t.rule_count) == [1762907, 103154, 35999, 42] and t.swaps == 1369236
+    assert t.last_prime == 999983
+    lib.gecm_tape_free(ctypes.byref(t))
+
+
+def test_prac_multiplier_choice_equals_oracle(lib):
+    orc = ctypes.CDLL(os.path.join(ROOT, "oracle", "libecm_oracle.so"))
+    orc.orc_prac_choice.argtypes = [ctypes.c_uint64]
+    lib.gecm_prac_best_multiplier.argtypes = [ctypes.c_uint64]
+    orc.orc_lucas_cost.restype = ctypes.c_double
+    orc.orc_lucas_cost.argtypes = [ctypes.c_uint64, ctypes.c_double]
+    lib.gecm_lucas_cost.restype = ctypes.c_double
+    lib.gecm_lucas_cost.argtypes = [ctypes.c_uint64, ctypes.c_double]
+    for c in list(range(3, 3000, 2)) + [999983, 99999989, 2 ** 31 - 1, 1000003]:
+        assert lib.gecm_prac_best_multiplier(c) == orc.orc_prac_choice(c)
+        assert lib.gecm_lucas_cost(c, 0.61803398874989485) == orc.orc_lucas_cost(c, 0.61803398874989485)
+
+
+def test_sieve(lib):
+    lib.gecm_primes_range.restype = ctypes.POINTER(ctypes.c_uint64)
+    lib.gecm_primes_range.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(ctypes.c_size_t)]
+    n = ctypes.c_size_t()
+    p = lib.gecm_primes_range(0, 100, ctypes.byref(n))
+    assert [p[i] for i in range(n.value)] == [2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37, 41, 43, 47, 53, 59, 61, 67,
+                                              71, 73, 79, 83, 89, 97]
+    p = lib.gecm_primes_range(0, 10 ** 7, ctypes.byref(n))
+    assert n.value == 664579
+    p = lib.gecm_primes_range(10 ** 8 - 100, 10 ** 8 + 100, ctypes.byref(n))
+    assert [p[i] for i in range(n.value)] == [99999931, 99999941, 99999959, 99999971, 99999989, 100000007,
+                                              100000037, 100000039, 100000049, 100000073, 100000081]
+    p = lib.gecm_primes_range(0, 10 ** 8, ctypes.byref(n))
+    assert n.value == 5761455                       # "cached 5761455 primes < 99999989" (main.c:583)
+
+
+def test_pair_map_equals_oracle_and_reference_counts(lib):
+    import pyecm
+    orc = ctypes.CDLL(os.path.join(ROOT, "oracle", "libecm_oracle.so"))
+    orc.orc_pair.restype = ctypes.c_uint32
+    PU = ctypes.POINTER(ctypes.c_uint32)
+    orc.orc_pair.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(PU),
+                             ctypes.POINTER(PU), PU, PU, PU]
+    for b1, b2, D, U in [(1000, 100000, 385, 4), (10000, 1000000, 2310, 16), (500, 50000, 210, 2), (60, 6000, 30, 1)]:
+        pm = pyecm.pair_primes(b1, b2, D, U)
+        v, u, am, pr, nq = PU(), PU(), ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32()
+        n = orc.orc_pair(b1, b2, D, U, ctypes.byref(v), ctypes.byref(u), ctypes.byref(am), ctypes.byref(pr), ctypes.byref(nq))
+        assert (pm.steps, pm.amin, pm.pairs, pm.primes) == (n, am.value, pr.value, nq.value)
+        assert all(pm.pairmap_v[i] == v[i] and pm.pairmap_u[i] == u[i] for i in range(n))
+        # coverage property (the reference's own `testcoverage` switch, ecm.c:2883-2900): every prime
+        # in [B1, B2) is hit by exactly the pair entries, walking the window as the device does
+        amin, covered = pm.amin, set()
+        for i in range(n):
+            if pm.pairmap_v[i] == 0 and pm.pairmap_u[i] == 0:
+                amin += U
+                continue
+            pa = pm.pairmap_v[i] - amin
+            assert 0 <= pa < 4 * U
+            centre = (2 * amin + pa) * D
+            covered.add(centre - pm.pairmap_u[i])
+            covered.add(centre + pm.pairmap_u[i])
+        sieve = [True] * (b2 + 1)
+        for i in range(2, int(b2 ** 0.5) + 1):
+            if sieve[i]:
+                for j in range(i * i, b2 + 1, i):
+                    sieve[j] = False
+        primes = [p for p in range(max(b1, 2), b2) if sieve[p]]
+        assert all(p in covered for p in primes)
+        lib.gecm_pairmap_release(ctypes.byref(pm))
+    # the reference's printout for config 1: "3008627 pairs found from 5682957 primes", amin = 216
+    pm = pyecm.pair_primes(1000000, 100000000, 2310, 16)
+    assert (pm.pairs, pm.primes, pm.amin) == (3008627, 5682957, 216)
+    lib.gecm_pairmap_release(ctypes.byref(pm))
+
+
+def test_mpl_bigint_kit(lib):
+    import random
+    MAXL = 136
+
+    class M(ctypes.Structure):
+        _fields_ = [("n", ctypes.c_int), ("d", ctypes.c_uint32 * MAXL)]
+
+    def to(v):
+        m = M()
+        assert lib.mpl_set_str(ctypes.byref(m), hex(v).encode()) == 0
+        return m
+
+    def fr(m):
+        return sum(m.d[i] << (32 * i) for i in range(m.n))
+
+    rng = random.Random(7)
+    for _ in range(300):
+        a = rng.getrandbits(rng.choice([1, 32, 33, 415, 831, 1023, 2000]))
+        b = rng.getrandbits(rng.choice([5, 32, 64, 65, 415, 1023])) | 1
+        A, B, q, r, g, iv = to(a), to(b), M(), M(), M(), M()
+        lib.mpl_divrem(ctypes.byref(q), ctypes.byref(r), ctypes.byref(A), ctypes.byref(B))
+        assert (fr(q), fr(r)) == divmod(a, b)
+        lib.mpl_gcd(ctypes.byref(g), ctypes.byref(A), ctypes.byref(B))
+        import math
+        assert fr(g) == math.gcd(a, b)
+        ok = lib.mpl_invmod(ctypes.byref(iv), ctypes.byref(A), ctypes.byref(B))
+        if b > 1:
+            assert bool(ok) == (math.gcd(a, b) == 1)
+            if ok:
+                assert fr(iv) == pow(a, -1, b)
+        buf = ctypes.create_string_buffer(MAXL * 10 + 2)
+        lib.mpl_get_dec(buf, ctypes.byref(A))
+        assert buf.value.decode() == str(a)
+        lib.mpl_get_hex(buf, ctypes.byref(A))
+        assert buf.value.decode() == "%x" % a

@@ -1,0 +1,53 @@
+"""GPU test of the avx-ecm command line (host/avx_ecm_main.c): same positional arguments as the
+reference, save_b1.txt byte-identical to the file the reference wrote (sha256 held in
+tests/golden/stage1.json), ecm_results.txt factor lines identical for an 8-curve run."""
+import hashlib
+import json
+import os
+import subprocess
+import tempfile
+
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+pytestmark = pytest.mark.gpu
+EXE = os.path.join(ROOT, "avx-ecm_amd", "avx-ecm")
+S1 = {c["name"]: c for c in json.load(open(os.path.join(GOLDEN, "stage1.json")))}
+
+
+def _run(args):
+    with tempfile.TemporaryDirectory() as d:
+        p = subprocess.run([EXE] + [str(a) for a in args], cwd=d, capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stdout + p.stderr
+        save = open(os.path.join(d, "save_b1.txt")).read() if os.path.exists(os.path.join(d, "save_b1.txt")) else ""
+        res = open(os.path.join(d, "ecm_results.txt")).read() if os.path.exists(os.path.join(d, "ecm_results.txt")) else ""
+    return p.stdout, save, [l for l in res.splitlines() if l.strip()]
+
+
+@pytest.mark.parametrize("name", ["n415_b1_10000", "n831_b1_10000", "K1N_two_full_batches_b1_500", "n415_b1_10000_b2_1e6"])
+def test_cli_save_file_and_results(name):
+    c = S1[name]
+    out, save, res = _run([c["N"], c["curves"], c["B1"], 1, c["B2"], c["sigma0"]])
+    assert hashlib.sha256(save.encode()).hexdigest() == c["save_sha256"]
+    assert "Stage 1 completed at prime" in out and "with %d point-adds and %d point-doubles" % (c["ptadds"], c["ptdups"]) in out
+    assert "Choosing MAXBITS = %d, NWORDS = %d" % (c["maxbits"], c["nwords"]) in out
+    if c["curves"] == 8:
+        assert res == c["results_lines"]
+    if c["stage2_counts"]:
+        assert "performed %d pt-adds, %d inversions, and %d pair-muls in stage 2" % tuple(c["stage2_counts"]) in out
+
+
+def test_cli_expression_input_config1():
+    """BASELINE configs[0]: the reference's own command line, input given as an expression"""
+    c = S1["config1_fib791"]
+    out, save, res = _run(["fib(791)/13/677/216416017", 8, 20000, 1, 20000, 1000])
+    n = int(c["save_lines"][0].split("N=0x")[1].split(";")[0], 16)
+    assert "commencing parallel ecm on %d" % n in out
+    assert "Choosing MAXBITS = 624, NWORDS = 12, NBLOCKS = 3 based on input size 508" in out
+    assert len(save.splitlines()) == 8 and all("N=0x%x;" % n in l for l in save.splitlines())
+
+
+def test_cli_usage():
+    p = subprocess.run([EXE], capture_output=True, text=True)
+    assert p.returncode == 1 and "usage: avx-ecm" in p.stdout

@@ -1,0 +1,125 @@
+"""GPU parity for stage 2 (ecm_stage2_init / ecm_stage2_pair, ecm.c:2201-2540) through the C ABI.
+
+  * accumulator (stg2acc) bit-identical to the oracle for the same (N, sigma, B1, B2, D, U): the
+    oracle itself is pinned to the reference by its counters and the factors it finds on the
+    reference's KATs (tests/test_oracle.py);
+  * factors found on the reference's own stage-2 KATs (test.csh / test_t35.csh via
+    tests/golden/stage1.json);
+  * counters (point adds, inversions, pair multiplications) equal to the reference's printout.
+"""
+import ctypes
+import json
+import os
+import re
+
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+pytestmark = pytest.mark.gpu
+
+S1 = {c["name"]: c for c in json.load(open(os.path.join(GOLDEN, "stage1.json")))}
+K1N = int(S1["K1"]["save_lines"][0].split("N=0x")[1].split(";")[0], 16)
+
+
+@pytest.fixture(scope="module")
+def orc():
+    L = ctypes.CDLL(os.path.join(ROOT, "oracle", "libecm_oracle.so"))
+    L.orc_create.restype = ctypes.c_void_p
+    L.orc_create.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    L.orc_destroy.argtypes = [ctypes.c_void_p]
+    L.orc_stage2.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32,
+                             ctypes.c_uint32, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t,
+                             ctypes.POINTER(ctypes.c_uint64)]
+    return L
+
+
+def _oracle(orc, n, sig, b1, b2, D, U, digitbits=52):
+    c = orc.orc_create(str(n).encode(), digitbits)
+    out = []
+    for s in sig:
+        acc = ctypes.create_string_buffer(4096)
+        fac = ctypes.create_string_buffer(2048)
+        cnt = (ctypes.c_uint64 * 3)()
+        orc.orc_stage2(c, s, b1, b2, D, U, acc, fac, len(fac), cnt)
+        out.append((int(acc.value, 16), int(fac.value) if fac.value else None, tuple(cnt)))
+    orc.orc_destroy(c)
+    return out
+
+
+@pytest.mark.parametrize("b1,b2,D,U,digitbits", [(2000, 100000, 385, 4, 52), (2000, 60000, 385, 16, 52),
+                                                  (5000, 300000, 2310, 2, 52), (300, 20000, 210, 3, 32)])
+def test_stage2_accumulator_equals_oracle(orc, b1, b2, D, U, digitbits):
+    import pyecm
+    sig = list(range(100, 100 + 66))           # ragged: 2 wavefronts
+    eng = pyecm.Engine(K1N, digitbits=digitbits)
+    eng.build_curves(sig)
+    eng.stage1(b1)
+    eng.stage2(b2, D, U)
+    acc = eng.download_acc()
+    st = eng.stage2_stats()
+    facs = [eng.stage2_factor(k) for k in range(len(sig))]
+    eng.close()
+    check = [0, 1, 63, 64, 65]
+    want = _oracle(orc, K1N, [sig[k] for k in check], b1, b2, D, U, digitbits)
+    for k, (wacc, wfac, wcnt) in zip(check, want):
+        assert acc[k] == wacc, "sigma %d" % sig[k]
+        assert (facs[k][0] if facs[k] else None) == wfac
+        assert (st.ptadds, st.numinv, st.paired) == wcnt
+
+
+def test_stage2_phase_api_matches_convenience(orc):
+    """gecm_stage2_init + gecm_pair_primes + gecm_stage2_pair (the reference's own call sequence)"""
+    import pyecm
+    sig = list(range(500, 508))
+    b1, b2 = 3000, 150000
+    eng = pyecm.Engine(K1N)
+    eng.build_curves(sig)
+    eng.stage1(b1)
+    eng.stage2_init(0, 0)
+    st = eng.stage2_stats()
+    assert (st.D, st.U, st.L) == (1155, 16, 32)          # main.c:848-851, U observed in the reference
+    pm = pyecm.pair_primes(b1, b2, st.D, st.U)
+    eng.stage2_pair(pm)
+    acc = eng.download_acc()
+    eng.close()
+    want = _oracle(orc, K1N, sig[:2], b1, b2, 1155, 16)
+    assert acc[0] == want[0][0] and acc[1] == want[1][0]
+
+
+def _kat(name, lanes=1):
+    import pyecm
+    case = S1[name]
+    n = int(case["save_lines"][0].split("N=0x")[1].split(";")[0], 16)
+    sig = [int(l.split("SIGMA=")[1].split(";")[0]) for l in case["save_lines"]][:lanes]
+    eng = pyecm.Engine(n)
+    eng.build_curves(sig)
+    eng.stage1(case["B1"])
+    eng.stage2(case["B2"])
+    st = eng.stage2_stats()
+    facs = [eng.stage2_factor(k) for k in range(len(sig))]
+    eng.close()
+    want = {}
+    for l in case["results_lines"]:
+        m = re.match(r"found (PRP|C)\d+ factor (\d+) in stage 2 .*vec (\d+), sigma (\d+)", l)
+        if m and int(m.group(3)) < lanes:
+            want[int(m.group(3))] = (int(m.group(2)), m.group(1) == "PRP")
+    got = {k: f for k, f in enumerate(facs) if f}
+    assert got == want
+    assert [st.ptadds, st.numinv, st.paired] == case["stage2_counts"]
+
+
+def test_stage2_kat_t35():
+    """test_t35.csh line 46: PRP31 factor in stage 2 at B1=1e6, B2=1e8"""
+    _kat("T35_46")
+
+
+def test_stage2_kat_k2_two_ranges():
+    """test.csh:7 (K2): PRP42 factor in stage 2, B2=1.5e8 spans two prime ranges"""
+    _kat("K2")
+
+
+def test_stage2_when_stage1_already_found_the_factor():
+    """random N with small factors: Z == 0 mod p after stage 1, so the batch inversion of stage 2
+    meets a non-invertible product (ecm.c:1927-1939); the factor is reported from that gcd"""
+    _kat("n415_b1_10000_b2_1e6", lanes=8)
