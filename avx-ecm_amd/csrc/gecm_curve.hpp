@@ -89,13 +89,41 @@ __device__ __forceinline__ void pt_add_uv(Fe<NL> &pp, Fe<NL> &mm, const Fe<NL> &
 // (doublings are ~10% of the steps) instead of occupying NL registers throughout.
 template <int NL>
 __device__ __forceinline__ void run_tape(const uint32_t *__restrict__ tape, uint32_t tape_len, Pt<NL> &A,
-                                         const uint32_t *__restrict__ S, size_t stride, size_t idx,
+                                         const uint32_t *__restrict__ S, size_t stride, uint32_t idx,
                                          const ModK<NL> &m)
 {
     Pt<NL> B = A, C = A;
-    for (uint32_t pc = 0; pc < tape_len; pc++) {
+    auto fetch = [&](uint32_t pc) -> uint32_t {
+        // one tape byte; past the end reads as NOP (the host pads the tape with zero words)
         uint32_t w = tape[pc >> 2];
-        uint32_t op = __builtin_amdgcn_readfirstlane((w >> ((pc & 3u) * 8u)) & 0xffu);
+        return __builtin_amdgcn_readfirstlane((w >> ((pc & 3u) * 8u)) & 0xffu);
+    };
+    for (uint32_t pc = 0; pc < tape_len; pc++) {
+        uint32_t op = fetch(pc);
+        // Fast path, as its own inner loop: rule 3 is 93% of the point additions at B1=1e6
+        // (1,762,907 of 1,902,102 steps) and comes in long runs.  Straight-line code with no
+        // operand selection; only A, B, C are live around it.
+        // ecm.c:617-630 (swap), 683-713: T = B + A (C); (B,T,C) <- (T,C,B)
+#ifndef GECM_NO_FASTPATH
+        while ((op & ~GECM_OP_SWAP) == (GECM_OP_STEP | GECM_OP_RULE3)) {
+            if (op & GECM_OP_SWAP) {
+                Pt<NL> t = A;
+                A = B;
+                B = t;
+            }
+            Fe<NL> s1, d1, s2, d2, pp, mm;
+            pt_sumdiff(s1, d1, B, m);
+            pt_sumdiff(s2, d2, A, m);
+            pt_add_uv(pp, mm, s1, d1, s2, d2, m);
+            Pt<NL> T;
+            fe_mul(T.X, pp, C.Z, m);
+            fe_mul(T.Z, mm, C.X, m);
+            C = B;
+            B = T;
+            pc++;
+            op = (pc < tape_len) ? fetch(pc) : GECM_OP_NOP;
+        }
+#endif
         if (op == GECM_OP_NOP) continue;
         uint32_t rule = op & GECM_OP_RULE_MASK;
         Fe<NL> s1, d1, s2, d2;

@@ -60,6 +60,9 @@ int gecm_dev_s2_pair(gecm_dev *d, const uint32_t *steps, uint32_t nsteps, uint32
                      uint64_t A0);
 /* canonical Montgomery-form accumulator and the failed-inversion gcd records ([limb][curve]) */
 int gecm_dev_s2_download(gecm_dev *d, uint32_t *acc, uint32_t *fail);
+/* factor scan on the device: which = 0 -> stage-1 Z, 1 -> stage-2 accumulator.  flags[curve] = 1 iff
+ * 1 < gcd(value, N) < N; g = the gcds ([limb][curve]); either output may be NULL. */
+int gecm_dev_gcd_scan(gecm_dev *d, int which, uint32_t *flags, uint32_t *g);
 size_t gecm_dev_s2_bytes(int nl, size_t ncurves, uint32_t npb, uint32_t L);
 
 #ifdef __cplusplus

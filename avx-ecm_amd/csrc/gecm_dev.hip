@@ -43,7 +43,8 @@ struct gecm_dev {
     std::vector<uint32_t> r3;
     uint32_t inv_iters = 0;
     uint32_t *dPbX = nullptr, *dBlk = nullptr, *dPd = nullptr, *dAcc = nullptr, *dFail = nullptr, *dKeep = nullptr;
-    uint32_t *dPa = nullptr, *dSteps = nullptr;
+    uint32_t *dPa = nullptr, *dSteps = nullptr, *dFlags = nullptr;
+    size_t flags_cap = 0;
     size_t s2_npb = 0, s2_L = 0, s2_stride = 0, steps_cap = 0, keep_cap = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -122,6 +123,7 @@ extern "C" void gecm_dev_close(gecm_dev *d)
     free_s2(d);
     (void)hipFree(d->dKeep);
     (void)hipFree(d->dSteps);
+    (void)hipFree(d->dFlags);
     (void)hipFree(d->dTape);
     if (d->ev0) (void)hipEventDestroy(d->ev0);
     if (d->ev1) (void)hipEventDestroy(d->ev1);
@@ -415,6 +417,37 @@ extern "C" int gecm_dev_s2_download(gecm_dev *d, uint32_t *acc, uint32_t *fail)
     }
     if (download_soa(d, acc, d->dAcc)) return -1;
     if (fail && download_soa(d, fail, d->dFail)) return -1;
+    HIPCHK(hipStreamSynchronize(d->stream));
+    return 0;
+}
+
+extern "C" int gecm_dev_gcd_scan(gecm_dev *d, int which, uint32_t *flags, uint32_t *g)
+{
+    HIPCHK(hipSetDevice(d->device));
+    const uint32_t *src = which == 0 ? d->dZ : d->dAcc;
+    if (!src || !d->stride || d->r3.empty()) {
+        g_err = "gecm_dev_gcd_scan: nothing to scan";
+        return -2;
+    }
+    if (d->flags_cap < d->stride) {
+        (void)hipFree(d->dFlags);
+        d->dFlags = nullptr;
+        HIPCHK(hipMalloc(&d->dFlags, d->stride * 4));
+        d->flags_cap = d->stride;
+    }
+    gecm_modconst mc = modconst(d);
+    switch (d->nl) {
+#define X(n)                                                                             \
+    case n:                                                                              \
+        gecm_launch_gcd_scan_##n(d->stream, &mc, src, d->dT0, d->dFlags, d->stride);     \
+        break;
+        GECM_NL_LIST(X)
+#undef X
+    }
+    HIPCHK(hipGetLastError());
+    if (flags && d->ncurves)
+        HIPCHK(hipMemcpyAsync(flags, d->dFlags, d->ncurves * 4, hipMemcpyDeviceToHost, d->stream));
+    if (g && download_soa(d, g, d->dT0)) return -1;
     HIPCHK(hipStreamSynchronize(d->stream));
     return 0;
 }

@@ -51,9 +51,17 @@ struct Fe {
 // s_nop the compiler pads after every asm statement.  The carry-out goes to vcc and is ignored
 // (28-bit limbs: the 64-bit column sum cannot overflow).  `_s`: y[] are wave-uniform (limbs of N)
 // and are read straight from SGPRs.
+#ifndef GECM_MAD_CHUNK
+#define GECM_MAD_CHUNK 14     // mads per asm statement (<= 14: an asm statement takes at most 30 operands)
+#endif
+
 template <int K>
 __device__ __forceinline__ void mad_chain_v(uint64_t &acc, const uint32_t (&x)[K], const uint32_t (&y)[K])
 {
+#ifdef GECM_CXX_MAD
+#pragma unroll
+    for (int k = 0; k < K; k++) acc += (uint64_t)x[k] * (uint64_t)y[k];
+#else
     if constexpr (K == 1) {
         asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(x[0]), "v"(y[0]) : "vcc");
     }
@@ -78,11 +86,34 @@ __device__ __forceinline__ void mad_chain_v(uint64_t &acc, const uint32_t (&x)[K
     else if constexpr (K == 8) {
         asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_mad_u64_u32 %0, vcc, %5, %6, %0\n\tv_mad_u64_u32 %0, vcc, %7, %8, %0\n\tv_mad_u64_u32 %0, vcc, %9, %10, %0\n\tv_mad_u64_u32 %0, vcc, %11, %12, %0\n\tv_mad_u64_u32 %0, vcc, %13, %14, %0\n\tv_mad_u64_u32 %0, vcc, %15, %16, %0" : "+v"(acc) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]), "v"(x[7]), "v"(y[7]) : "vcc");
     }
+    else if constexpr (K == 9) {
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_mad_u64_u32 %0, vcc, %5, %6, %0\n\tv_mad_u64_u32 %0, vcc, %7, %8, %0\n\tv_mad_u64_u32 %0, vcc, %9, %10, %0\n\tv_mad_u64_u32 %0, vcc, %11, %12, %0\n\tv_mad_u64_u32 %0, vcc, %13, %14, %0\n\tv_mad_u64_u32 %0, vcc, %15, %16, %0\n\tv_mad_u64_u32 %0, vcc, %17, %18, %0" : "+v"(acc) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]), "v"(x[7]), "v"(y[7]), "v"(x[8]), "v"(y[8]) : "vcc");
+    }
+    else if constexpr (K == 10) {
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_mad_u64_u32 %0, vcc, %5, %6, %0\n\tv_mad_u64_u32 %0, vcc, %7, %8, %0\n\tv_mad_u64_u32 %0, vcc, %9, %10, %0\n\tv_mad_u64_u32 %0, vcc, %11, %12, %0\n\tv_mad_u64_u32 %0, vcc, %13, %14, %0\n\tv_mad_u64_u32 %0, vcc, %15, %16, %0\n\tv_mad_u64_u32 %0, vcc, %17, %18, %0\n\tv_mad_u64_u32 %0, vcc, %19, %20, %0" : "+v"(acc) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]), "v"(x[7]), "v"(y[7]), "v"(x[8]), "v"(y[8]), "v"(x[9]), "v"(y[9]) : "vcc");
+    }
+    else if constexpr (K == 11) {
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_mad_u64_u32 %0, vcc, %5, %6, %0\n\tv_mad_u64_u32 %0, vcc, %7, %8, %0\n\tv_mad_u64_u32 %0, vcc, %9, %10, %0\n\tv_mad_u64_u32 %0, vcc, %11, %12, %0\n\tv_mad_u64_u32 %0, vcc, %13, %14, %0\n\tv_mad_u64_u32 %0, vcc, %15, %16, %0\n\tv_mad_u64_u32 %0, vcc, %17, %18, %0\n\tv_mad_u64_u32 %0, vcc, %19, %20, %0\n\tv_mad_u64_u32 %0, vcc, %21, %22, %0" : "+v"(acc) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]), "v"(x[7]), "v"(y[7]), "v"(x[8]), "v"(y[8]), "v"(x[9]), "v"(y[9]), "v"(x[10]), "v"(y[10]) : "vcc");
+    }
+    else if constexpr (K == 12) {
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_mad_u64_u32 %0, vcc, %5, %6, %0\n\tv_mad_u64_u32 %0, vcc, %7, %8, %0\n\tv_mad_u64_u32 %0, vcc, %9, %10, %0\n\tv_mad_u64_u32 %0, vcc, %11, %12, %0\n\tv_mad_u64_u32 %0, vcc, %13, %14, %0\n\tv_mad_u64_u32 %0, vcc, %15, %16, %0\n\tv_mad_u64_u32 %0, vcc, %17, %18, %0\n\tv_mad_u64_u32 %0, vcc, %19, %20, %0\n\tv_mad_u64_u32 %0, vcc, %21, %22, %0\n\tv_mad_u64_u32 %0, vcc, %23, %24, %0" : "+v"(acc) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]), "v"(x[7]), "v"(y[7]), "v"(x[8]), "v"(y[8]), "v"(x[9]), "v"(y[9]), "v"(x[10]), "v"(y[10]), "v"(x[11]), "v"(y[11]) : "vcc");
+    }
+    else if constexpr (K == 13) {
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_mad_u64_u32 %0, vcc, %5, %6, %0\n\tv_mad_u64_u32 %0, vcc, %7, %8, %0\n\tv_mad_u64_u32 %0, vcc, %9, %10, %0\n\tv_mad_u64_u32 %0, vcc, %11, %12, %0\n\tv_mad_u64_u32 %0, vcc, %13, %14, %0\n\tv_mad_u64_u32 %0, vcc, %15, %16, %0\n\tv_mad_u64_u32 %0, vcc, %17, %18, %0\n\tv_mad_u64_u32 %0, vcc, %19, %20, %0\n\tv_mad_u64_u32 %0, vcc, %21, %22, %0\n\tv_mad_u64_u32 %0, vcc, %23, %24, %0\n\tv_mad_u64_u32 %0, vcc, %25, %26, %0" : "+v"(acc) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]), "v"(x[7]), "v"(y[7]), "v"(x[8]), "v"(y[8]), "v"(x[9]), "v"(y[9]), "v"(x[10]), "v"(y[10]), "v"(x[11]), "v"(y[11]), "v"(x[12]), "v"(y[12]) : "vcc");
+    }
+    else if constexpr (K == 14) {
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_mad_u64_u32 %0, vcc, %5, %6, %0\n\tv_mad_u64_u32 %0, vcc, %7, %8, %0\n\tv_mad_u64_u32 %0, vcc, %9, %10, %0\n\tv_mad_u64_u32 %0, vcc, %11, %12, %0\n\tv_mad_u64_u32 %0, vcc, %13, %14, %0\n\tv_mad_u64_u32 %0, vcc, %15, %16, %0\n\tv_mad_u64_u32 %0, vcc, %17, %18, %0\n\tv_mad_u64_u32 %0, vcc, %19, %20, %0\n\tv_mad_u64_u32 %0, vcc, %21, %22, %0\n\tv_mad_u64_u32 %0, vcc, %23, %24, %0\n\tv_mad_u64_u32 %0, vcc, %25, %26, %0\n\tv_mad_u64_u32 %0, vcc, %27, %28, %0" : "+v"(acc) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]), "v"(x[7]), "v"(y[7]), "v"(x[8]), "v"(y[8]), "v"(x[9]), "v"(y[9]), "v"(x[10]), "v"(y[10]), "v"(x[11]), "v"(y[11]), "v"(x[12]), "v"(y[12]), "v"(x[13]), "v"(y[13]) : "vcc");
+    }
+#endif
 }
 
 template <int K>
 __device__ __forceinline__ void mad_chain_s(uint64_t &acc, const uint32_t (&x)[K], const uint32_t (&y)[K])
 {
+#ifdef GECM_CXX_MAD
+#pragma unroll
+    for (int k = 0; k < K; k++) acc += (uint64_t)x[k] * (uint64_t)y[k];
+#else
     if constexpr (K == 1) {
         asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(x[0]), "s"(y[0]) : "vcc");
     }
@@ -107,6 +138,25 @@ __device__ __forceinline__ void mad_chain_s(uint64_t &acc, const uint32_t (&x)[K
     else if constexpr (K == 8) {
         asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_mad_u64_u32 %0, vcc, %5, %6, %0\n\tv_mad_u64_u32 %0, vcc, %7, %8, %0\n\tv_mad_u64_u32 %0, vcc, %9, %10, %0\n\tv_mad_u64_u32 %0, vcc, %11, %12, %0\n\tv_mad_u64_u32 %0, vcc, %13, %14, %0\n\tv_mad_u64_u32 %0, vcc, %15, %16, %0" : "+v"(acc) : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]), "v"(x[4]), "s"(y[4]), "v"(x[5]), "s"(y[5]), "v"(x[6]), "s"(y[6]), "v"(x[7]), "s"(y[7]) : "vcc");
     }
+    else if constexpr (K == 9) {
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_mad_u64_u32 %0, vcc, %5, %6, %0\n\tv_mad_u64_u32 %0, vcc, %7, %8, %0\n\tv_mad_u64_u32 %0, vcc, %9, %10, %0\n\tv_mad_u64_u32 %0, vcc, %11, %12, %0\n\tv_mad_u64_u32 %0, vcc, %13, %14, %0\n\tv_mad_u64_u32 %0, vcc, %15, %16, %0\n\tv_mad_u64_u32 %0, vcc, %17, %18, %0" : "+v"(acc) : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]), "v"(x[4]), "s"(y[4]), "v"(x[5]), "s"(y[5]), "v"(x[6]), "s"(y[6]), "v"(x[7]), "s"(y[7]), "v"(x[8]), "s"(y[8]) : "vcc");
+    }
+    else if constexpr (K == 10) {
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_mad_u64_u32 %0, vcc, %5, %6, %0\n\tv_mad_u64_u32 %0, vcc, %7, %8, %0\n\tv_mad_u64_u32 %0, vcc, %9, %10, %0\n\tv_mad_u64_u32 %0, vcc, %11, %12, %0\n\tv_mad_u64_u32 %0, vcc, %13, %14, %0\n\tv_mad_u64_u32 %0, vcc, %15, %16, %0\n\tv_mad_u64_u32 %0, vcc, %17, %18, %0\n\tv_mad_u64_u32 %0, vcc, %19, %20, %0" : "+v"(acc) : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]), "v"(x[4]), "s"(y[4]), "v"(x[5]), "s"(y[5]), "v"(x[6]), "s"(y[6]), "v"(x[7]), "s"(y[7]), "v"(x[8]), "s"(y[8]), "v"(x[9]), "s"(y[9]) : "vcc");
+    }
+    else if constexpr (K == 11) {
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_mad_u64_u32 %0, vcc, %5, %6, %0\n\tv_mad_u64_u32 %0, vcc, %7, %8, %0\n\tv_mad_u64_u32 %0, vcc, %9, %10, %0\n\tv_mad_u64_u32 %0, vcc, %11, %12, %0\n\tv_mad_u64_u32 %0, vcc, %13, %14, %0\n\tv_mad_u64_u32 %0, vcc, %15, %16, %0\n\tv_mad_u64_u32 %0, vcc, %17, %18, %0\n\tv_mad_u64_u32 %0, vcc, %19, %20, %0\n\tv_mad_u64_u32 %0, vcc, %21, %22, %0" : "+v"(acc) : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]), "v"(x[4]), "s"(y[4]), "v"(x[5]), "s"(y[5]), "v"(x[6]), "s"(y[6]), "v"(x[7]), "s"(y[7]), "v"(x[8]), "s"(y[8]), "v"(x[9]), "s"(y[9]), "v"(x[10]), "s"(y[10]) : "vcc");
+    }
+    else if constexpr (K == 12) {
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_mad_u64_u32 %0, vcc, %5, %6, %0\n\tv_mad_u64_u32 %0, vcc, %7, %8, %0\n\tv_mad_u64_u32 %0, vcc, %9, %10, %0\n\tv_mad_u64_u32 %0, vcc, %11, %12, %0\n\tv_mad_u64_u32 %0, vcc, %13, %14, %0\n\tv_mad_u64_u32 %0, vcc, %15, %16, %0\n\tv_mad_u64_u32 %0, vcc, %17, %18, %0\n\tv_mad_u64_u32 %0, vcc, %19, %20, %0\n\tv_mad_u64_u32 %0, vcc, %21, %22, %0\n\tv_mad_u64_u32 %0, vcc, %23, %24, %0" : "+v"(acc) : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]), "v"(x[4]), "s"(y[4]), "v"(x[5]), "s"(y[5]), "v"(x[6]), "s"(y[6]), "v"(x[7]), "s"(y[7]), "v"(x[8]), "s"(y[8]), "v"(x[9]), "s"(y[9]), "v"(x[10]), "s"(y[10]), "v"(x[11]), "s"(y[11]) : "vcc");
+    }
+    else if constexpr (K == 13) {
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_mad_u64_u32 %0, vcc, %5, %6, %0\n\tv_mad_u64_u32 %0, vcc, %7, %8, %0\n\tv_mad_u64_u32 %0, vcc, %9, %10, %0\n\tv_mad_u64_u32 %0, vcc, %11, %12, %0\n\tv_mad_u64_u32 %0, vcc, %13, %14, %0\n\tv_mad_u64_u32 %0, vcc, %15, %16, %0\n\tv_mad_u64_u32 %0, vcc, %17, %18, %0\n\tv_mad_u64_u32 %0, vcc, %19, %20, %0\n\tv_mad_u64_u32 %0, vcc, %21, %22, %0\n\tv_mad_u64_u32 %0, vcc, %23, %24, %0\n\tv_mad_u64_u32 %0, vcc, %25, %26, %0" : "+v"(acc) : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]), "v"(x[4]), "s"(y[4]), "v"(x[5]), "s"(y[5]), "v"(x[6]), "s"(y[6]), "v"(x[7]), "s"(y[7]), "v"(x[8]), "s"(y[8]), "v"(x[9]), "s"(y[9]), "v"(x[10]), "s"(y[10]), "v"(x[11]), "s"(y[11]), "v"(x[12]), "s"(y[12]) : "vcc");
+    }
+    else if constexpr (K == 14) {
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_mad_u64_u32 %0, vcc, %5, %6, %0\n\tv_mad_u64_u32 %0, vcc, %7, %8, %0\n\tv_mad_u64_u32 %0, vcc, %9, %10, %0\n\tv_mad_u64_u32 %0, vcc, %11, %12, %0\n\tv_mad_u64_u32 %0, vcc, %13, %14, %0\n\tv_mad_u64_u32 %0, vcc, %15, %16, %0\n\tv_mad_u64_u32 %0, vcc, %17, %18, %0\n\tv_mad_u64_u32 %0, vcc, %19, %20, %0\n\tv_mad_u64_u32 %0, vcc, %21, %22, %0\n\tv_mad_u64_u32 %0, vcc, %23, %24, %0\n\tv_mad_u64_u32 %0, vcc, %25, %26, %0\n\tv_mad_u64_u32 %0, vcc, %27, %28, %0" : "+v"(acc) : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]), "v"(x[4]), "s"(y[4]), "v"(x[5]), "s"(y[5]), "v"(x[6]), "s"(y[6]), "v"(x[7]), "s"(y[7]), "v"(x[8]), "s"(y[8]), "v"(x[9]), "s"(y[9]), "v"(x[10]), "s"(y[10]), "v"(x[11]), "s"(y[11]), "v"(x[12]), "s"(y[12]), "v"(x[13]), "s"(y[13]) : "vcc");
+    }
+#endif
 }
 
 template <int K> struct IC { static constexpr int value = K; };
@@ -124,9 +174,9 @@ template <int C, int I0, int I1, int NA, int NB>
 __device__ __forceinline__ void col_vv(uint64_t &acc, const uint32_t (&a)[NA], const uint32_t (&b)[NB])
 {
     constexpr int K = I1 - I0;
-    if constexpr (K > 8) {
-        col_vv<C, I0, I0 + 8>(acc, a, b);
-        col_vv<C, I0 + 8, I1>(acc, a, b);
+    if constexpr (K > GECM_MAD_CHUNK) {
+        col_vv<C, I0, I0 + GECM_MAD_CHUNK>(acc, a, b);
+        col_vv<C, I0 + GECM_MAD_CHUNK, I1>(acc, a, b);
     } else if constexpr (K > 0) {
         uint32_t x[K], y[K];
 #pragma unroll
@@ -140,9 +190,9 @@ template <int C, int I0, int I1, int NA, int NB>
 __device__ __forceinline__ void col_vs(uint64_t &acc, const uint32_t (&q)[NA], const uint32_t (&n)[NB])
 {
     constexpr int K = I1 - I0;
-    if constexpr (K > 8) {
-        col_vs<C, I0, I0 + 8>(acc, q, n);
-        col_vs<C, I0 + 8, I1>(acc, q, n);
+    if constexpr (K > GECM_MAD_CHUNK) {
+        col_vs<C, I0, I0 + GECM_MAD_CHUNK>(acc, q, n);
+        col_vs<C, I0 + GECM_MAD_CHUNK, I1>(acc, q, n);
     } else if constexpr (K > 0) {
         uint32_t x[K], y[K];
 #pragma unroll
@@ -294,17 +344,28 @@ __device__ __forceinline__ void fe_canonical_mont(Fe<NL> &r, const Fe<NL> &a, co
     fe_cond_sub_n(r, m);
 }
 
-// coalesced SoA access: element [limb][curve], consecutive lanes -> consecutive curves
+// coalesced SoA access: element [limb][curve], consecutive lanes -> consecutive curves.
+// The row pointer (base + limb*stride) is wave-uniform and the lane index is a 32-bit offset, so
+// each access is `global_load_dword v, v_off, s[row]` (SGPR base + VGPR offset): no per-limb 64-bit
+// address pairs are kept live in VGPRs.
 template <int NL>
-__device__ __forceinline__ void fe_load(Fe<NL> &r, const uint32_t *__restrict__ base, size_t stride, size_t idx)
+__device__ __forceinline__ void fe_load(Fe<NL> &r, const uint32_t *__restrict__ base, size_t stride, uint32_t idx)
 {
+    const uint32_t boff = idx * 4u;       // 32-bit byte offset: lets the SGPR-base addressing form match
 #pragma unroll
-    for (int i = 0; i < NL; i++) r.v[i] = base[(size_t)i * stride + idx];
+    for (int i = 0; i < NL; i++) {
+        const char *row = (const char *)(base + (size_t)i * stride);
+        r.v[i] = *(const uint32_t *)(row + boff);
+    }
 }
 
 template <int NL>
-__device__ __forceinline__ void fe_store(uint32_t *__restrict__ base, size_t stride, size_t idx, const Fe<NL> &r)
+__device__ __forceinline__ void fe_store(uint32_t *__restrict__ base, size_t stride, uint32_t idx, const Fe<NL> &r)
 {
+    const uint32_t boff = idx * 4u;
 #pragma unroll
-    for (int i = 0; i < NL; i++) base[(size_t)i * stride + idx] = r.v[i];
+    for (int i = 0; i < NL; i++) {
+        char *row = (char *)(base + (size_t)i * stride);
+        *(uint32_t *)(row + boff) = r.v[i];
+    }
 }

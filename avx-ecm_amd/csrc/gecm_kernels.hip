@@ -24,7 +24,7 @@ __global__ void __launch_bounds__(64, 2)
 k_stage1(const uint32_t *__restrict__ tape, uint32_t tape_len, uint32_t *__restrict__ X,
          uint32_t *__restrict__ Z, const uint32_t *__restrict__ S, size_t stride, ModArgs<NL> a)
 {
-    size_t idx = (size_t)blockIdx.x * 64 + threadIdx.x;
+    uint32_t idx = blockIdx.x * 64u + threadIdx.x;
     Pt<NL> P;
     fe_load(P.X, X, stride, idx);
     fe_load(P.Z, Z, stride, idx);
@@ -41,7 +41,7 @@ __global__ void __launch_bounds__(64)
 k_from_mont(const uint32_t *__restrict__ X, const uint32_t *__restrict__ Z, uint32_t *__restrict__ ox,
             uint32_t *__restrict__ oz, size_t stride, ModArgs<NL> a)
 {
-    size_t idx = (size_t)blockIdx.x * 64 + threadIdx.x;
+    uint32_t idx = blockIdx.x * 64u + threadIdx.x;
     Fe<NL> x, z, r;
     fe_load(x, X, stride, idx);
     fe_load(z, Z, stride, idx);
@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(64)
 k_l0(int op, const uint32_t *__restrict__ A, const uint32_t *__restrict__ B, uint32_t *__restrict__ C,
      uint32_t *__restrict__ D, size_t stride, ModArgs<NL> a, Fe<NL> fix)
 {
-    size_t idx = (size_t)blockIdx.x * 64 + threadIdx.x;
+    uint32_t idx = blockIdx.x * 64u + threadIdx.x;
     Fe<NL> x, y, r, t;
     fe_load(x, A, stride, idx);
     fe_load(y, B, stride, idx);
@@ -88,13 +88,37 @@ k_l0(int op, const uint32_t *__restrict__ A, const uint32_t *__restrict__ B, uin
 template <int NL>
 __global__ void __launch_bounds__(64, 2) k_s2_init(S2InitArgs a, S2Const<NL> k)
 {
-    s2_init<NL>(a, k, (size_t)blockIdx.x * 64 + threadIdx.x);
+    s2_init<NL>(a, k, blockIdx.x * 64u + threadIdx.x);
 }
 
 template <int NL>
 __global__ void __launch_bounds__(64, 2) k_s2_pair(S2PairArgs a, S2Const<NL> k)
 {
-    s2_pair<NL>(a, k, (size_t)blockIdx.x * 64 + threadIdx.x);
+    s2_pair<NL>(a, k, blockIdx.x * 64u + threadIdx.x);
+}
+
+// ---------------------------------------------------------------- factor scan
+// check_factor (ecm.c:2542-2557) for every curve on the device: g = gcd(v, N) by the same
+// fixed-iteration binary algorithm the stage-2 inversion uses; flag = 1 iff 1 < g < N.
+// v is any representative (Montgomery form or not: R is a power of two, N is odd).
+template <int NL>
+__global__ void __launch_bounds__(64, 2)
+k_gcd_scan(const uint32_t *__restrict__ V, uint32_t *__restrict__ G, uint32_t *__restrict__ flags, size_t stride,
+           S2Const<NL> k)
+{
+    uint32_t idx = blockIdx.x * 64u + threadIdx.x;
+    Fe<NL> v, c, t, g;
+    fe_load(v, V, stride, idx);
+    fe_canonical_mont(c, v, k.one, k.m);
+    fe_invert(t, g, c, k.m, k.inv_iters);
+    bool is_one = g.v[0] == 1u, is_n = true;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        if (i > 0) is_one = is_one && g.v[i] == 0;
+        is_n = is_n && g.v[i] == k.m.n[i];
+    }
+    fe_store(G, stride, idx, g);
+    flags[idx] = (!is_one && !is_n) ? 1u : 0u;
 }
 
 // ---------------------------------------------------------------- launchers (C linkage)
@@ -173,4 +197,11 @@ extern "C" void CAT(gecm_launch_s2_pair_, GECM_NL)(void *stream, const gecm_modc
     a.steps = h->steps; a.nsteps = h->nsteps; a.U = h->U; a.L = h->L; a.D = h->D; a.A0 = h->A0; a.stride = h->stride;
     hipLaunchKernelGGL(k_s2_pair<GECM_NL>, dim3((unsigned)(h->stride / 64)), dim3(64), 0, (hipStream_t)stream, a,
                        make_s2<GECM_NL>(mc));
+}
+
+extern "C" void CAT(gecm_launch_gcd_scan_, GECM_NL)(void *stream, const gecm_modconst *mc, const uint32_t *V,
+                                                     uint32_t *G, uint32_t *flags, size_t stride)
+{
+    hipLaunchKernelGGL(k_gcd_scan<GECM_NL>, dim3((unsigned)(stride / 64)), dim3(64), 0, (hipStream_t)stream, V, G, flags,
+                       stride, make_s2<GECM_NL>(mc));
 }

@@ -42,7 +42,9 @@ typedef struct {
                              const uint32_t *B, uint32_t *C, uint32_t *D, size_t stride,                  \
                              const uint32_t *fix);                                                        \
     void gecm_launch_s2_init_##nl(void *stream, const gecm_modconst *mc, const gecm_s2_init_args *h);     \
-    void gecm_launch_s2_pair_##nl(void *stream, const gecm_modconst *mc, const gecm_s2_pair_args *h);
+    void gecm_launch_s2_pair_##nl(void *stream, const gecm_modconst *mc, const gecm_s2_pair_args *h);     \
+    void gecm_launch_gcd_scan_##nl(void *stream, const gecm_modconst *mc, const uint32_t *V, uint32_t *G, \
+                                   uint32_t *flags, size_t stride);
 GECM_NL_LIST(GECM_DECL)
 #undef GECM_DECL
 

@@ -34,12 +34,12 @@ struct S2Const {
 
 // entry `e` of a table [entry][limb][curve]
 template <int NL>
-__device__ __forceinline__ void tb_load(Fe<NL> &r, const uint32_t *__restrict__ base, size_t stride, size_t idx, size_t e)
+__device__ __forceinline__ void tb_load(Fe<NL> &r, const uint32_t *__restrict__ base, size_t stride, uint32_t idx, size_t e)
 {
     fe_load(r, base + e * (size_t)NL * stride, stride, idx);
 }
 template <int NL>
-__device__ __forceinline__ void tb_store(uint32_t *__restrict__ base, size_t stride, size_t idx, size_t e, const Fe<NL> &r)
+__device__ __forceinline__ void tb_store(uint32_t *__restrict__ base, size_t stride, uint32_t idx, size_t e, const Fe<NL> &r)
 {
     fe_store(base + e * (size_t)NL * stride, stride, idx, r);
 }
@@ -143,7 +143,7 @@ __device__ __noinline__ bool fe_invert(Fe<NL> &r, Fe<NL> &g, const Fe<NL> &x, co
 // On failure r = 0 and *fail receives gcd(x R mod N, N) = gcd(x, N) (first failure wins).
 template <int NL>
 __device__ __forceinline__ void fe_inv_mont(Fe<NL> &r, const Fe<NL> &a, const S2Const<NL> &k, uint32_t *__restrict__ fail,
-                                            size_t stride, size_t idx)
+                                            size_t stride, uint32_t idx)
 {
     Fe<NL> c, t, g;
     fe_canonical_mont(c, a, k.one, k.m);          // canonical x R
@@ -166,7 +166,7 @@ __device__ __forceinline__ void fe_inv_mont(Fe<NL> &r, const Fe<NL> &a, const S2
 template <int NL>
 __device__ __forceinline__ void block_normalise(uint32_t *__restrict__ out, size_t e0, const uint32_t *__restrict__ bx,
                                                 const uint32_t *__restrict__ bz, uint32_t *__restrict__ bp, uint32_t n,
-                                                const S2Const<NL> &k, uint32_t *__restrict__ fail, size_t stride, size_t idx)
+                                                const S2Const<NL> &k, uint32_t *__restrict__ fail, size_t stride, uint32_t idx)
 {
     Fe<NL> acc, z, x, t;
     tb_load(acc, bz, stride, idx, 0);
@@ -238,7 +238,7 @@ struct S2InitArgs {
 
 // ecm_stage2_init, ecm.c:2201-2340
 template <int NL>
-__device__ __forceinline__ void s2_init(const S2InitArgs &a, const S2Const<NL> &k, size_t idx)
+__device__ __forceinline__ void s2_init(const S2InitArgs &a, const S2Const<NL> &k, uint32_t idx)
 {
     const ModK<NL> &m = k.m;
     const size_t stride = a.stride;
@@ -304,7 +304,7 @@ struct S2PairArgs {
 // normalise ring slots [first, first+n) (window positions): PaI = PaX / PaZ
 template <int NL>
 __device__ __forceinline__ void ring_normalise(const S2PairArgs &a, uint32_t w0, uint32_t first, uint32_t n,
-                                               const S2Const<NL> &k, size_t idx)
+                                               const S2Const<NL> &k, uint32_t idx)
 {
     const size_t stride = a.stride;
     const uint32_t ring = 2 * a.L;
@@ -337,7 +337,7 @@ __device__ __forceinline__ void ring_normalise(const S2PairArgs &a, uint32_t w0,
 // Pa[pos] = Pa[pos-1] + Pd, difference Pa[pos-2]   (ecm.c:2412-2416, 2473-2476)
 template <int NL>
 __device__ __forceinline__ void ring_step(const S2PairArgs &a, uint32_t w0, uint32_t pos, const Fe<NL> &sD, const Fe<NL> &dD,
-                                          const ModK<NL> &m, size_t idx)
+                                          const ModK<NL> &m, uint32_t idx)
 {
     const size_t stride = a.stride;
     const uint32_t ring = 2 * a.L;
@@ -358,7 +358,7 @@ __device__ __forceinline__ void ring_step(const S2PairArgs &a, uint32_t w0, uint
 
 // ecm_stage2_pair, ecm.c:2342-2540
 template <int NL>
-__device__ __forceinline__ void s2_pair(const S2PairArgs &a, const S2Const<NL> &k, size_t idx)
+__device__ __forceinline__ void s2_pair(const S2PairArgs &a, const S2Const<NL> &k, uint32_t idx)
 {
     const ModK<NL> &m = k.m;
     const size_t stride = a.stride;

@@ -196,10 +196,12 @@ int main(int argc, char **argv)
         /* save + factor scan in global curve order, ecm.c:1319-1388 */
         FILE *save = fopen("save_b1.txt", "a");
         if (!save) printf("could not open save_b1.txt for appending, Stage 1 data will not be saved\n");
-        for (int g = 0; g < gpus; g++)
+        for (int g = 0; g < gpus; g++) {
+            /* whole-batch gcd scan on the device, then format only the flagged curves */
+            if (jobs[g].ncurves && gecm_scan_factors(jobs[g].ctx, 1, NULL) < 0) { fprintf(stderr, "%s\n", gecm_last_error()); return 2; }
             for (size_t k = 0; k < jobs[g].ncurves; k++) {
                 int prp = 0;
-                int r = gecm_stage1_factor(jobs[g].ctx, k, fac, sizeof fac, &prp);
+                int r = gecm_curve_flag(jobs[g].ctx, 1, k) ? gecm_stage1_factor(jobs[g].ctx, k, fac, sizeof fac, &prp) : 0;
                 if (r == 1) {
                     size_t curve = done + jobs[g].first + k;
                     printf("\nfound %s%d factor %s in stage 1 (B1 = %lu): thread %d, vec %zu, sigma %lu\n",
@@ -216,6 +218,7 @@ int main(int argc, char **argv)
                 }
                 if (save && gecm_format_save_line(jobs[g].ctx, k, line, sizeof line) > 0) fputs(line, save);
             }
+        }
         if (save) fclose(save);
         fflush(stdout);
         if (do_stage2) {                                                         /* ecm.c:1394-1528 */
@@ -227,10 +230,11 @@ int main(int argc, char **argv)
             printf("\nStage 2 took %1.4f seconds\n", now() - t);                 /* ecm.c:1481 */
             printf("performed %lu pt-adds, %lu inversions, and %lu pair-muls in stage 2\n",
                    (unsigned long)s2.ptadds, (unsigned long)s2.numinv, (unsigned long)s2.paired);   /* ecm.c:1482 */
-            for (int g = 0; g < gpus; g++)
+            for (int g = 0; g < gpus; g++) {
+                if (jobs[g].ncurves && gecm_scan_factors(jobs[g].ctx, 2, NULL) < 0) { fprintf(stderr, "%s\n", gecm_last_error()); return 2; }
                 for (size_t k = 0; k < jobs[g].ncurves; k++) {
                     int prp = 0;
-                    if (gecm_stage2_factor(jobs[g].ctx, k, fac, sizeof fac, &prp) == 1) {
+                    if (gecm_curve_flag(jobs[g].ctx, 2, k) && gecm_stage2_factor(jobs[g].ctx, k, fac, sizeof fac, &prp) == 1) {
                         size_t curve = done + jobs[g].first + k;
                         printf("\nfound %s%d factor %s in stage 2 (B2 = %lu): thread %d, vec %zu, sigma %lu\n",
                                prp ? "PRP" : "C", (int)strlen(fac), fac, (unsigned long)B2, g, k,
@@ -245,6 +249,7 @@ int main(int argc, char **argv)
                         found = 1;
                     }
                 }
+            }
         }
         free(sig);
     }

@@ -59,6 +59,7 @@ struct gecm_ctx {
     int s2_ready;
     uint32_t *hacc, *hfail;
     int have_acc;
+    uint32_t *flags[2];      /* per-curve result of the last device factor scan: stage 1, stage 2 */
     uint64_t s2_ptadds, s2_numinv, s2_paired, s2_devinv;
     uint32_t s2_amin_last;
 };
@@ -168,6 +169,8 @@ int gecm_create(gecm_ctx **out, int device, const char *n_str, int digitbits)
 static void free_batch(gecm_ctx *c)
 {
     free(c->sigma); free(c->bad); free(c->hx); free(c->hz); free(c->hacc); free(c->hfail);
+    free(c->flags[0]); free(c->flags[1]);
+    c->flags[0] = c->flags[1] = NULL;
     c->sigma = NULL; c->bad = NULL; c->hx = c->hz = NULL; c->hacc = c->hfail = NULL;
     c->have_acc = 0; c->s2_ready = 0;
     c->batch = 0;
@@ -720,4 +723,36 @@ int gecm_stage2_factor(gecm_ctx *c, size_t k, char *dec, size_t declen, int *is_
         return 1;
     }
     return 0;
+}
+
+/* ---- device factor scan ------------------------------------------------------------------- */
+int gecm_scan_factors(gecm_ctx *c, int stage, size_t *first)
+{
+    if (!c || c->batch == 0 || (stage != 1 && stage != 2)) { set_err("gecm_scan_factors: bad argument"); return GECM_ERR_ARG; }
+    if (stage == 2 && !c->s2_ready) { set_err("gecm_scan_factors: no stage-2 state"); return GECM_ERR_STATE; }
+    uint32_t **f = &c->flags[stage - 1];
+    if (!*f) *f = (uint32_t *)calloc(c->batch, sizeof(uint32_t));
+    if (!*f) return GECM_ERR_NOMEM;
+    if (gecm_dev_gcd_scan(c->dev, stage - 1, *f, NULL)) { set_err("gecm_scan_factors: %s", gecm_dev_error()); return GECM_ERR_DEVICE; }
+    size_t n = 0, lo = c->batch;
+    if (stage == 2) {
+        /* a failed batch inversion also marks its curve (ecm.c:1927-1939) */
+        int rc = fetch_acc(c);
+        if (rc) return rc;
+        for (size_t k = 0; k < c->batch; k++) {
+            mpl_t g;
+            mpl_from_limbs32(&g, c->hfail + k, c->batch, c->nl, LIMB_BITS);
+            if (!mpl_is_zero(&g)) (*f)[k] = (mpl_cmp_u64(&g, 1) > 0 && mpl_cmp(&g, &c->N) != 0);
+        }
+    }
+    for (size_t k = 0; k < c->batch; k++)
+        if ((*f)[k]) { n++; if (k < lo) lo = k; }
+    if (first) *first = lo;
+    return (int)(n > 0x7fffffff ? 0x7fffffff : n);
+}
+
+int gecm_curve_flag(const gecm_ctx *c, int stage, size_t k)
+{
+    if (!c || (stage != 1 && stage != 2) || k >= c->batch || !c->flags[stage - 1]) return 0;
+    return (int)c->flags[stage - 1][k];
 }

@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "libgecm.so")
+LIB_PATH = os.environ.get("GECM_LIB") or os.path.join(os.path.dirname(_HERE), "libgecm.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError("libgecm.so not built: run `make -C avx-ecm_amd -j8` (or __graft_entry__.build())")
@@ -86,6 +86,9 @@ _sig("gecm_stage2", c_int, c_void_p, c_u64, ctypes.c_uint32, ctypes.c_uint32)
 _sig("gecm_get_stage2_stats", c_int, c_void_p, ctypes.POINTER(Stage2Stats))
 _sig("gecm_download_acc", c_int, c_void_p, c_void_p)
 _sig("gecm_stage2_factor", c_int, c_void_p, c_size_t, c_char_p, c_size_t, ctypes.POINTER(c_int))
+_sig("gecm_scan_factors", c_int, c_void_p, c_int, ctypes.POINTER(c_size_t))
+_sig("gecm_curve_flag", c_int, c_void_p, c_int, c_size_t)
+EXPORTS += ["gecm_scan_factors", "gecm_curve_flag"]
 EXPORTS += ["gecm_stage2_init", "gecm_pair_primes", "gecm_pairmap_release", "gecm_stage2_pair", "gecm_stage2",
             "gecm_get_stage2_stats", "gecm_download_acc", "gecm_stage2_factor"]
 
@@ -232,6 +235,15 @@ class Engine:
         prp = c_int(0)
         rc = _chk(lib.gecm_stage1_factor(self._h, k, buf, len(buf), ctypes.byref(prp)), "gecm_stage1_factor")
         return (int(buf.value.decode()), bool(prp.value)) if rc == 1 else None
+
+    def scan_factors(self, stage=1):
+        """device factor scan: (number of curves with a factor, lowest such index or None)"""
+        first = c_size_t(0)
+        n = _chk(lib.gecm_scan_factors(self._h, stage, ctypes.byref(first)), "gecm_scan_factors")
+        return n, (first.value if n else None)
+
+    def curve_flag(self, stage, k):
+        return bool(lib.gecm_curve_flag(self._h, stage, k))
 
     # ---- stage 2 ----
     def stage2(self, b2, D=0, U=0):

@@ -126,12 +126,15 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     import pyecm
 
+    from pyecm import shard
     n = random.Random(a.bits).getrandbits(a.bits) | (1 << (a.bits - 1)) | 1
     eng = pyecm.Engine(n, digitbits=52, device=local_rank)
-    # host-side split of the curve batch: rank g owns sigma in [1000 + g*C, 1000 + (g+1)*C)
-    sig0 = 1000 + rank * a.curves
-    eng.build_curves(list(range(sig0, sig0 + a.curves)))
-    found = torch.zeros(3, dtype=torch.int64, device="cuda:%d" % local_rank)
+    # host-side split of the curve batch (pyecm/shard.py): rank g owns the contiguous global curve
+    # indices [g*C, (g+1)*C), sigma = 1000 + index
+    total = a.curves * world
+    lo, hi = shard.shard_bounds(total, rank, world)
+    eng.build_curves(shard.shard_sigmas(1000, total, rank, world))
+    dev = "cuda:%d" % local_rank
 
     def barrier():
         if dist is not None:
@@ -140,12 +143,16 @@ def main():
 
     kernel_ms = []
 
+    found_log = []
+
     def step():
         eng.stage1(a.b1, sync=True)
         kernel_ms.append(eng.last_kernel_ms())
-        if dist is not None:
-            # the one collective of the path: "factor found" flag {found, rank, curve}, max-reduced
-            dist.all_reduce(found, op=dist.ReduceOp.MAX)
+        # factor scan of the whole batch on the device (check_factor, ecm.c:2542-2557), then the ONE
+        # collective of the path: max-reduce of the found record (lowest global curve with a factor)
+        nf, first = eng.scan_factors(1)
+        g = shard.allreduce_found(dist, None if first is None else lo + first, total, device=dev)
+        found_log.append((nf, g))
 
     for _ in range(a.warmup):
         step()
@@ -180,10 +187,19 @@ def main():
         kms = sum(kernel_ms) / len(kernel_ms)
         mads_per_launch = mads * a.curves
         achieved = mads_per_launch / (kms * 1e-3)
+        traffic = None
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
+            if pm.get("kernel") == "k_stage1<%d>" % cfg.dev_limbs and pm.get("curves") == a.curves and pm.get("B1") == a.b1:
+                traffic = pm["hbm_bytes_per_launch_corrected"]
+        except Exception:
+            pass
         roof = {
             "bound": "valu", "kernel": "k_stage1<%d>" % cfg.dev_limbs,
             "achieved": achieved / 1e12, "peak": PEAK_MAD_PER_S / 1e12, "unit": "Tmad/s (v_mad_u64_u32 lane-ops)",
-            "frac": achieved / PEAK_MAD_PER_S, "traffic": None,
+            "frac": achieved / PEAK_MAD_PER_S, "traffic": traffic,
+            "traffic_note": "HBM bytes per launch from rocprofv3 PMC passes of this command (profiles/), FETCH_SIZE x2 "
+                            "per the gfx950 correction; null if no matching profile is committed",
             "kernel_ms_avg": kms, "mads_per_curve": mads,
             "survey_units": {"limb_products_52bit_per_curve": w52,
                              "achieved_T52/s": w52 * a.curves / (kms * 1e-3) / 1e12,
@@ -196,11 +212,15 @@ def main():
             "unit": "curves/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32 (28-bit limbs, 64-bit accumulate)", "data": "synthetic",
-            "config": {"workload": "%d curves per GPU per step, %d-bit random odd N (seed %d), B1=%d, "
-                                   "sigma=1000.., stage 1 only; reference limb format 52-bit NWORDS=%d"
-                                   % (a.curves, a.bits, a.bits, a.b1, cfg.nwords),
+            "config": {"workload": "%d curves per GPU per step (= %d sub-batches of the 4096 curves of BASELINE "
+                                   "configs[1], in one launch: one curve per lane needs 131072 curves to put 2 "
+                                   "wavefronts on each of the 1024 SIMDs), %d-bit random odd N (seed %d), B1=%d, "
+                                   "sigma=1000.., stage 1 + device factor scan; reference limb format 52-bit NWORDS=%d"
+                                   % (a.curves, a.curves // 4096, a.bits, a.bits, a.b1, cfg.nwords),
                        "curves_per_gpu": a.curves, "bits": a.bits, "B1": a.b1,
-                       "parallelism": "curve batch split across %d GPU(s), 1 RCCL all-reduce of the found flag per step" % world},
+                       "curves_with_factor_last_step": found_log[-1][0],
+                       "parallelism": "curve batch split across %d GPU(s) on the host, no data-path collective, "
+                                      "1 all-reduce (RCCL) of the found record per step" % world},
             "roofline": roof,
         }
         if small:

@@ -117,6 +117,15 @@ int gecm_format_save_line(gecm_ctx *ctx, size_t k, char *buf, size_t buflen);
  * 1 < g < N, else 0 (g == N is "no factor", ecm.c:2549-2553).                                 */
 int gecm_stage1_factor(gecm_ctx *ctx, size_t k, char *dec, size_t declen, int *is_prp);
 
+/* Whole-batch factor scan on the device (the reference scans lane by lane on the host,
+ * ecm.c:1323-1370, 1485-1528): stage = 1 checks gcd(Z_k, N) after stage 1, stage = 2 checks
+ * gcd(acc_k, N) after stage 2, for every curve at once.  Returns the number of curves with a factor
+ * (>= 0) and, if first != NULL, the lowest such curve index (or batch if none).  The per-curve
+ * functions above/below then format the factors of the flagged curves.                          */
+int gecm_scan_factors(gecm_ctx *ctx, int stage, size_t *first);
+/* 1 if curve k was flagged by the last gecm_scan_factors call of that stage, else 0 */
+int gecm_curve_flag(const gecm_ctx *ctx, int stage, size_t k);
+
 /* ---- L1 phase 2: stage-2 init (ecm_stage2_init, ecm.c:2201-2340) --------------------------
  * Q = the stage-1 result resident on the device.  Builds the baby-step table Pb[map[j]] = [j]Q for
  * j <= U*D with gcd(j, D) = 1 (X/Z-normalised by batch inversion, ecm.c:2322), Pd = [D]Q and

@@ -123,3 +123,24 @@ def test_stage2_when_stage1_already_found_the_factor():
     """random N with small factors: Z == 0 mod p after stage 1, so the batch inversion of stage 2
     meets a non-invertible product (ecm.c:1927-1939); the factor is reported from that gcd"""
     _kat("n415_b1_10000_b2_1e6", lanes=8)
+
+
+def test_device_factor_scan_equals_per_curve_host_gcd():
+    """gecm_scan_factors (device gcd of the whole batch) flags exactly the curves whose host
+    gcd(Z, N) / gcd(acc, N) reports a factor (check_factor, ecm.c:2542-2557)"""
+    import pyecm
+    n = 1000003 * K1N                 # one 20-bit prime factor: some curves find it at B1=300, most do not
+    sig = list(range(1000, 1000 + 130))
+    eng = pyecm.Engine(n)
+    eng.build_curves(sig)
+    eng.stage1(300)
+    host = [eng.stage1_factor(k) is not None for k in range(len(sig))]
+    nf, first = eng.scan_factors(1)
+    dev = [eng.curve_flag(1, k) for k in range(len(sig))]
+    assert dev == host and nf == sum(host) and 0 < nf < len(sig)
+    assert first == host.index(True)
+    eng.stage2(3000, 0, 2)
+    host2 = [eng.stage2_factor(k) is not None for k in range(len(sig))]
+    nf2, first2 = eng.scan_factors(2)
+    assert [eng.curve_flag(2, k) for k in range(len(sig))] == host2 and nf2 == sum(host2)
+    eng.close()
