@@ -98,8 +98,12 @@ __device__ __forceinline__ void run_tape(const uint32_t *__restrict__ tape, uint
         uint32_t w = tape[pc >> 2];
         return __builtin_amdgcn_readfirstlane((w >> ((pc & 3u) * 8u)) & 0xffu);
     };
+    // The tape byte of the NEXT event is fetched at the start of the current one, so its scalar-load
+    // latency hides behind ~13k cycles of arithmetic instead of being paid at every step.
+    uint32_t nxt = tape_len ? fetch(0) : GECM_OP_NOP;
     for (uint32_t pc = 0; pc < tape_len; pc++) {
-        uint32_t op = fetch(pc);
+        uint32_t op = nxt;
+        nxt = (pc + 1 < tape_len) ? fetch(pc + 1) : GECM_OP_NOP;
         // Fast path, as its own inner loop: rule 3 is 93% of the point additions at B1=1e6
         // (1,762,907 of 1,902,102 steps) and comes in long runs.  Straight-line code with no
         // operand selection; only A, B, C are live around it.
@@ -121,80 +125,72 @@ __device__ __forceinline__ void run_tape(const uint32_t *__restrict__ tape, uint
             C = B;
             B = T;
             pc++;
-            op = (pc < tape_len) ? fetch(pc) : GECM_OP_NOP;
+            op = nxt;
+            nxt = (pc + 1 < tape_len) ? fetch(pc + 1) : GECM_OP_NOP;
         }
 #endif
         if (op == GECM_OP_NOP) continue;
-        uint32_t rule = op & GECM_OP_RULE_MASK;
-        Fe<NL> s1, d1, s2, d2;
-        bool is_step = op >= GECM_OP_STEP;
-        bool do_add = is_step || op == GECM_OP_PRAC_END;
-        bool do_dup = (is_step && rule != GECM_OP_RULE3) || op == GECM_OP_PRAC_BEGIN;
-        if (is_step) {
-            if (op & GECM_OP_SWAP) {   // ecm.c:617-630
-                Pt<NL> t = A;
-                A = B;
-                B = t;
-            }
-            if (rule == GECM_OP_RULE3 || rule == GECM_OP_RULE4) {
-                // ecm.c:688-691 / 718-721: (s1,d1)<-B, (s2,d2)<-A, difference C
-                pt_sumdiff(s1, d1, B, m);
-                pt_sumdiff(s2, d2, A, m);
-            } else if (rule == GECM_OP_RULE5) {
-                // ecm.c:732-735: (s1,d1)<-C, (s2,d2)<-A, difference B
-                pt_sumdiff(s1, d1, C, m);
-                pt_sumdiff(s2, d2, A, m);
-            } else {
-                // rule 9, ecm.c:857-860: (s1,d1)<-C, (s2,d2)<-B, difference A
-                pt_sumdiff(s1, d1, C, m);
-                pt_sumdiff(s2, d2, B, m);
-            }
-        } else if (op == GECM_OP_PRAC_BEGIN) {
-            // ecm.c:603-613 (and the 2-power loop ecm.c:1817-1821)
+        // Slow path (rules 4, 5, 9, PRAC_BEGIN, PRAC_END: 14% of the events).  Every one of them is
+        // "T = B' + A' (difference C'), D = 2A'" for a renaming (A',B',C') of the three points, so
+        // the points are permuted into that canonical order with register moves, ONE straight-line
+        // add+double core runs, and the results are written back through the inverse renaming.
+        // No operand is selected inside the arithmetic, which keeps register pressure low.
+        const uint32_t rule = op & GECM_OP_RULE_MASK;
+        const bool is_step = op >= GECM_OP_STEP;
+        const bool do_add = op != GECM_OP_PRAC_BEGIN;
+        const bool do_dup = op != GECM_OP_PRAC_END;
+        if (is_step && (op & GECM_OP_SWAP)) {       // ecm.c:617-630
+            Pt<NL> t = A;
+            A = B;
+            B = t;
+        }
+        if (is_step && rule == GECM_OP_RULE5) {     // C = C + A (B); A = 2A  (ecm.c:728-740): B <-> C
+            Pt<NL> t = B;
+            B = C;
+            C = t;
+        } else if (is_step && rule == GECM_OP_RULE9) {   // C = C + B (A); B = 2B  (ecm.c:853-865): (A,B,C) <- (B,C,A)
+            Pt<NL> t = A;
+            A = B;
+            B = C;
+            C = t;
+        } else if (op == GECM_OP_PRAC_BEGIN) {      // B = C = A  (ecm.c:603-608)
             B = A;
             C = A;
-            pt_sumdiff(s2, d2, A, m);
-        } else {
-            // PRAC_END, ecm.c:868-873: (s1,d1)<-A, (s2,d2)<-B, difference C
-            pt_sumdiff(s1, d1, A, m);
-            pt_sumdiff(s2, d2, B, m);
         }
         Pt<NL> T, D;
-        if (do_add) {
-            Fe<NL> pp, mm, pd;
-            pt_add_uv(pp, mm, s1, d1, s2, d2, m);
-            bool pd_b = is_step && rule == GECM_OP_RULE5, pd_a = is_step && rule == GECM_OP_RULE9;
-            if (pd_b) pd = B.Z; else if (pd_a) pd = A.Z; else pd = C.Z;
-            fe_mul(T.X, pp, pd, m);    // Z- * (U+V)^2   ecm.c:438
-            if (pd_b) pd = B.X; else if (pd_a) pd = A.X; else pd = C.X;
-            fe_mul(T.Z, mm, pd, m);    // X- * (U-V)^2   ecm.c:439
-        }
-        if (do_dup) {
-            // (s2,d2) again from the point being doubled (unchanged so far): cheaper than
-            // keeping them live across the addition.
-            Fe<NL> s, d, s4;
-            if (is_step && rule == GECM_OP_RULE9) pt_sumdiff(s, d, B, m); else pt_sumdiff(s, d, A, m);
-            fe_load(s4, S, stride, idx);
-            pt_dup(D, s, d, s4, m);
-        }
-        if (is_step) {
-            if (rule == GECM_OP_RULE3) {        // (B,T,C) <- (T,C,B)   ecm.c:704-711
-                C = B;
-                B = T;
-            } else if (rule == GECM_OP_RULE4) { // B = T; A = 2A
-                B = T;
-                A = D;
-            } else if (rule == GECM_OP_RULE5) { // C = T; A = 2A
-                C = T;
-                A = D;
-            } else {                             // C = T; B = 2B
-                C = T;
-                B = D;
+        {
+            Fe<NL> s1, d1, s2, d2;
+            pt_sumdiff(s2, d2, A, m);
+            if (do_add) {                            // T = B + A, difference C  (ecm.c:417-440)
+                Fe<NL> pp, mm;
+                pt_sumdiff(s1, d1, B, m);
+                pt_add_uv(pp, mm, s1, d1, s2, d2, m);
+                fe_mul(T.X, pp, C.Z, m);
+                fe_mul(T.Z, mm, C.X, m);
             }
-        } else if (op == GECM_OP_PRAC_BEGIN) {
-            A = D;
-        } else {
+            if (do_dup) {                            // D = 2A  (ecm.c:447-454)
+                Fe<NL> s4;
+                fe_load(s4, S, stride, idx);
+                pt_dup(D, s2, d2, s4, m);
+            }
+        }
+        if (op == GECM_OP_PRAC_END) {               // P = A + B (C)   ecm.c:868-873
             A = T;
+        } else if (op == GECM_OP_PRAC_BEGIN) {      // A = 2A          ecm.c:613
+            A = D;
+        } else if (rule == GECM_OP_RULE4) {         // B = T; A = D    ecm.c:721-722
+            B = T;
+            A = D;
+        } else if (rule == GECM_OP_RULE5) {         // C = T (sits in B); A = D; undo B <-> C
+            Pt<NL> t = C;
+            C = T;
+            B = t;
+            A = D;
+        } else {                                    // rule 9: C = T, B = D; undo (A,B,C) <- (B,C,A)
+            Pt<NL> oldA = C;
+            C = T;
+            B = D;
+            A = oldA;
         }
     }
 }

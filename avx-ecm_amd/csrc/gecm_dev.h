@@ -54,16 +54,18 @@ int gecm_dev_set_s2const(gecm_dev *d, const uint32_t *r3, uint32_t inv_iters);
 /* ecm_stage2_init: baby-step table (npb entries, X/Z normalised), Pd = [D]Q, acc = one.
  * keep: bitmap over j in [0, umax], bit set iff j is stored.  L = ring half-size (2L giant steps). */
 int gecm_dev_s2_init(gecm_dev *d, const uint32_t *keep, size_t keep_words, uint32_t umax, uint32_t D,
-                     uint32_t npb, uint32_t L);
-/* ecm_stage2_pair for one range: steps = nsteps pairs (pa, pb); pa = 0xffffffff -> window shift. */
-int gecm_dev_s2_pair(gecm_dev *d, const uint32_t *steps, uint32_t nsteps, uint32_t U, uint32_t L, uint32_t D,
-                     uint64_t A0);
+                     uint32_t npb, uint32_t G, uint32_t ring_size);
+/* ecm_stage2_pair for one range: steps = nsteps words pairs: (0xffffffff, n) = generate the next n
+ * giant steps (n <= G), else (ring slot, table index).  G = chunk size, ring_size = power of two. */
+int gecm_dev_s2_pair(gecm_dev *d, const uint32_t *steps, uint32_t nsteps, uint32_t D, uint32_t G,
+                     uint32_t ring_size, uint64_t A0);
+#define GECM_S2_BLK 256   /* baby-step normalisation block (= S2_BLK in gecm_stage2.hpp) */
 /* canonical Montgomery-form accumulator and the failed-inversion gcd records ([limb][curve]) */
 int gecm_dev_s2_download(gecm_dev *d, uint32_t *acc, uint32_t *fail);
 /* factor scan on the device: which = 0 -> stage-1 Z, 1 -> stage-2 accumulator.  flags[curve] = 1 iff
  * 1 < gcd(value, N) < N; g = the gcds ([limb][curve]); either output may be NULL. */
 int gecm_dev_gcd_scan(gecm_dev *d, int which, uint32_t *flags, uint32_t *g);
-size_t gecm_dev_s2_bytes(int nl, size_t ncurves, uint32_t npb, uint32_t L);
+size_t gecm_dev_s2_bytes(int nl, size_t ncurves, uint32_t npb, uint32_t G, uint32_t ring_size);
 
 #ifdef __cplusplus
 }

@@ -45,7 +45,7 @@ struct gecm_dev {
     uint32_t *dPbX = nullptr, *dBlk = nullptr, *dPd = nullptr, *dAcc = nullptr, *dFail = nullptr, *dKeep = nullptr;
     uint32_t *dPa = nullptr, *dSteps = nullptr, *dFlags = nullptr;
     size_t flags_cap = 0;
-    size_t s2_npb = 0, s2_L = 0, s2_stride = 0, steps_cap = 0, keep_cap = 0;
+    size_t s2_npb = 0, s2_G = 0, s2_ring = 0, s2_stride = 0, steps_cap = 0, keep_cap = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_ms = 0.f;
@@ -112,7 +112,7 @@ static void free_s2(gecm_dev *d)
     (void)hipFree(d->dPbX); (void)hipFree(d->dBlk); (void)hipFree(d->dPd); (void)hipFree(d->dAcc);
     (void)hipFree(d->dFail); (void)hipFree(d->dPa);
     d->dPbX = d->dBlk = d->dPd = d->dAcc = d->dFail = d->dPa = nullptr;
-    d->s2_npb = d->s2_L = d->s2_stride = 0;
+    d->s2_npb = d->s2_G = d->s2_ring = d->s2_stride = 0;
 }
 
 extern "C" void gecm_dev_close(gecm_dev *d)
@@ -309,15 +309,15 @@ extern "C" int gecm_dev_set_s2const(gecm_dev *d, const uint32_t *r3, uint32_t in
     return 0;
 }
 
-extern "C" size_t gecm_dev_s2_bytes(int nl, size_t ncurves, uint32_t npb, uint32_t L)
+extern "C" size_t gecm_dev_s2_bytes(int nl, size_t ncurves, uint32_t npb, uint32_t G, uint32_t ring_size)
 {
     size_t stride = (ncurves + 63) / 64 * 64;
     size_t coord = (size_t)nl * stride * 4;
-    return coord * ((size_t)npb + 3 * 32 + 2 + 2 + 3 * 2 * (size_t)L + 2 * (size_t)L);
+    return coord * ((size_t)npb + 3 * GECM_S2_BLK + 2 + 2 + 2 * ((size_t)G + 2) + (size_t)G + (size_t)ring_size);
 }
 
 extern "C" int gecm_dev_s2_init(gecm_dev *d, const uint32_t *keep, size_t keep_words, uint32_t umax, uint32_t D,
-                                uint32_t npb, uint32_t L)
+                                uint32_t npb, uint32_t G, uint32_t ring_size)
 {
     HIPCHK(hipSetDevice(d->device));
     if (!d->stride || d->r3.empty()) {
@@ -325,15 +325,16 @@ extern "C" int gecm_dev_s2_init(gecm_dev *d, const uint32_t *keep, size_t keep_w
         return -2;
     }
     const size_t coord = (size_t)d->nl * d->stride * sizeof(uint32_t);
-    if (d->s2_npb != npb || d->s2_L != L || d->s2_stride != d->stride) {
+    if (d->s2_npb != npb || d->s2_G != G || d->s2_ring != ring_size || d->s2_stride != d->stride) {
         free_s2(d);
         HIPCHK(hipMalloc(&d->dPbX, coord * npb));
-        HIPCHK(hipMalloc(&d->dBlk, coord * 3 * 32));             // bx, bz, bp: S2_BLK entries each
+        HIPCHK(hipMalloc(&d->dBlk, coord * 3 * GECM_S2_BLK));    // bx, bz, bp: S2_BLK entries each
         HIPCHK(hipMalloc(&d->dPd, coord * 2));
         HIPCHK(hipMalloc(&d->dAcc, coord));
         HIPCHK(hipMalloc(&d->dFail, coord));
-        HIPCHK(hipMalloc(&d->dPa, coord * (3 * 2 * (size_t)L + 2 * (size_t)L)));   // PaX, PaZ, PaI, prefix scratch
-        d->s2_npb = npb; d->s2_L = L; d->s2_stride = d->stride;
+        // giant steps: gx, gz (G+2 entries each), gp (G), ring (ring_size)
+        HIPCHK(hipMalloc(&d->dPa, coord * (2 * ((size_t)G + 2) + (size_t)G + (size_t)ring_size)));
+        d->s2_npb = npb; d->s2_G = G; d->s2_ring = ring_size; d->s2_stride = d->stride;
     }
     if (keep_words > d->keep_cap) {
         (void)hipFree(d->dKeep);
@@ -347,7 +348,7 @@ extern "C" int gecm_dev_s2_init(gecm_dev *d, const uint32_t *keep, size_t keep_w
     gecm_s2_init_args a;
     a.X = d->dX; a.Z = d->dZ; a.S = d->dS;
     a.PbX = d->dPbX;
-    a.bx = d->dBlk; a.bz = d->dBlk + (coord / 4) * 32; a.bp = d->dBlk + (coord / 4) * 64;
+    a.bx = d->dBlk; a.bz = d->dBlk + (coord / 4) * GECM_S2_BLK; a.bp = d->dBlk + (coord / 4) * 2 * GECM_S2_BLK;
     a.PdX = d->dPd; a.PdZ = d->dPd + coord / 4;
     a.acc = d->dAcc; a.fail = d->dFail; a.keep = d->dKeep;
     a.umax = umax; a.D = D; a.stride = d->stride;
@@ -367,12 +368,12 @@ extern "C" int gecm_dev_s2_init(gecm_dev *d, const uint32_t *keep, size_t keep_w
     return 0;
 }
 
-extern "C" int gecm_dev_s2_pair(gecm_dev *d, const uint32_t *steps, uint32_t nsteps, uint32_t U, uint32_t L, uint32_t D,
-                                uint64_t A0)
+extern "C" int gecm_dev_s2_pair(gecm_dev *d, const uint32_t *steps, uint32_t nsteps, uint32_t D, uint32_t G,
+                                uint32_t ring_size, uint64_t A0)
 {
     HIPCHK(hipSetDevice(d->device));
-    if (!d->dPbX || d->s2_L != L) {
-        g_err = "gecm_dev_s2_pair: stage-2 init has not run (or L changed)";
+    if (!d->dPbX || d->s2_G != G || d->s2_ring != ring_size || (ring_size & (ring_size - 1))) {
+        g_err = "gecm_dev_s2_pair: stage-2 init has not run (or chunk/ring size changed)";
         return -2;
     }
     const size_t coord = (size_t)d->nl * d->stride * sizeof(uint32_t);
@@ -387,11 +388,10 @@ extern "C" int gecm_dev_s2_pair(gecm_dev *d, const uint32_t *steps, uint32_t nst
     gecm_s2_pair_args a;
     a.X = d->dX; a.Z = d->dZ; a.S = d->dS; a.PbX = d->dPbX;
     a.PdX = d->dPd; a.PdZ = d->dPd + coord / 4;
-    const size_t ring = 2 * (size_t)L;
-    a.PaX = d->dPa; a.PaZ = d->dPa + (coord / 4) * ring; a.PaI = d->dPa + (coord / 4) * 2 * ring;
-    a.bp = d->dPa + (coord / 4) * 3 * ring;
-    a.acc = d->dAcc; a.fail = d->dFail; a.steps = d->dSteps;
-    a.nsteps = nsteps; a.U = U; a.L = L; a.D = D; a.A0 = A0; a.stride = d->stride;
+    const size_t cw = coord / 4;
+    a.gx = d->dPa; a.gz = a.gx + cw * ((size_t)G + 2); a.gp = a.gz + cw * ((size_t)G + 2); a.ring = a.gp + cw * (size_t)G;
+    a.acc = d->dAcc; a.fail = d->dFail; a.steps = d->dSteps; a.host_steps = steps;
+    a.nsteps = nsteps; a.D = D; a.G = G; a.ring_size = ring_size; a.A0 = A0; a.stride = d->stride;
     gecm_modconst mc = modconst(d);
     HIPCHK(hipEventRecord(d->ev0, d->stream));
     switch (d->nl) {

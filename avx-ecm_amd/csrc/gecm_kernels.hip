@@ -91,10 +91,18 @@ __global__ void __launch_bounds__(64, 2) k_s2_init(S2InitArgs a, S2Const<NL> k)
     s2_init<NL>(a, k, blockIdx.x * 64u + threadIdx.x);
 }
 
+// giant steps [first_abs, first_abs+n): generate + normalise into the ring
 template <int NL>
-__global__ void __launch_bounds__(64, 2) k_s2_pair(S2PairArgs a, S2Const<NL> k)
+__global__ void __launch_bounds__(64, 2) k_s2_gen(S2PairArgs a, uint32_t first_abs, uint32_t n, S2Const<NL> k)
 {
-    s2_pair<NL>(a, k, blockIdx.x * 64u + threadIdx.x);
+    giant_chunk<NL>(a, first_abs, n, first_abs == 0, k, blockIdx.x * 64u + threadIdx.x);
+}
+
+// pair walk over tape entries [first, first+count)
+template <int NL>
+__global__ void __launch_bounds__(64, 2) k_s2_pairs(S2PairArgs a, uint32_t first, uint32_t count, S2Const<NL> k)
+{
+    s2_pairs<NL>(a, first, count, k, blockIdx.x * 64u + threadIdx.x);
 }
 
 // ---------------------------------------------------------------- factor scan
@@ -193,10 +201,27 @@ extern "C" void CAT(gecm_launch_s2_pair_, GECM_NL)(void *stream, const gecm_modc
 {
     S2PairArgs a;
     a.X = h->X; a.Z = h->Z; a.S = h->S; a.PbX = h->PbX; a.PdX = h->PdX; a.PdZ = h->PdZ;
-    a.PaX = h->PaX; a.PaZ = h->PaZ; a.PaI = h->PaI; a.bp = h->bp; a.acc = h->acc; a.fail = h->fail;
-    a.steps = h->steps; a.nsteps = h->nsteps; a.U = h->U; a.L = h->L; a.D = h->D; a.A0 = h->A0; a.stride = h->stride;
-    hipLaunchKernelGGL(k_s2_pair<GECM_NL>, dim3((unsigned)(h->stride / 64)), dim3(64), 0, (hipStream_t)stream, a,
-                       make_s2<GECM_NL>(mc));
+    a.gx = h->gx; a.gz = h->gz; a.gp = h->gp; a.ring = h->ring; a.acc = h->acc; a.fail = h->fail;
+    a.steps = h->steps; a.nsteps = h->nsteps; a.D = h->D; a.G = h->G; a.ring_size = h->ring_size; a.A0 = h->A0;
+    a.stride = h->stride;
+    // the tape on the host decides the launch sequence: one k_s2_gen per "generate" mark, one
+    // k_s2_pairs per run of pairs between marks (~84 + 84 launches per 1e8 range)
+    const dim3 grid((unsigned)(h->stride / 64)), block(64);
+    const S2Const<GECM_NL> k = make_s2<GECM_NL>(mc);
+    uint32_t generated = 0, i = 0;
+    while (i < h->nsteps) {
+        if (h->host_steps[2 * i] == S2_STEP_GEN) {
+            uint32_t n = h->host_steps[2 * i + 1];
+            hipLaunchKernelGGL(k_s2_gen<GECM_NL>, grid, block, 0, (hipStream_t)stream, a, generated, n, k);
+            generated += n;
+            i++;
+        } else {
+            uint32_t j = i;
+            while (j < h->nsteps && h->host_steps[2 * j] != S2_STEP_GEN) j++;
+            hipLaunchKernelGGL(k_s2_pairs<GECM_NL>, grid, block, 0, (hipStream_t)stream, a, i, j - i, k);
+            i = j;
+        }
+    }
 }
 
 extern "C" void CAT(gecm_launch_gcd_scan_, GECM_NL)(void *stream, const gecm_modconst *mc, const uint32_t *V,

@@ -8,7 +8,11 @@ extern "C" {
 #endif
 
 /* limb counts built into the library; keep in sync with the Makefile's NLS */
+#ifdef GECM_DEV_NL15
+#define GECM_NL_LIST(X) X(15)      /* `make DEV=1`: quick developer build, 416-bit class only */
+#else
 #define GECM_NL_LIST(X) X(8) X(12) X(15) X(19) X(23) X(26) X(30) X(34) X(37)
+#endif
 
 typedef struct {
     const uint32_t *n, *kp, *one, *r3;
@@ -25,9 +29,10 @@ typedef struct {
 
 typedef struct {
     const uint32_t *X, *Z, *S, *PbX, *PdX, *PdZ;
-    uint32_t *PaX, *PaZ, *PaI, *bp, *acc, *fail;
-    const uint32_t *steps;
-    uint32_t nsteps, U, L, D;
+    uint32_t *gx, *gz, *gp, *ring, *acc, *fail;
+    const uint32_t *steps;        /* device copy of the tape */
+    const uint32_t *host_steps;   /* host copy: the launcher splits it at the "generate" marks */
+    uint32_t nsteps, D, G, ring_size;
     uint64_t A0;
     size_t stride;
 } gecm_s2_pair_args;

@@ -18,11 +18,13 @@
 //     curve instead of writing it into stg2acc (ecm.c:1927-1939);
 //   * the baby-step table is normalised in blocks of S2_BLK entries (one inversion per block)
 //     rather than in one 7.7k-entry pass, so only the normalised X of each entry is kept in HBM;
-//   * the giant-step window is a ring (no copies on a window shift, ecm.c:2461-2469).
+//   * giant steps are produced in chunks of G steps with one inversion per chunk into a ring of
+//     normalised X/Z (the reference re-inverts 2U new steps at every window shift,
+//     ecm.c:2458-2502: 1,341 inversions at B2 = 1e8; here 84 + 31 for the table).
 #pragma once
 #include "gecm_curve.hpp"
 
-#define S2_BLK 32
+#define S2_BLK 256
 
 template <int NL>
 struct S2Const {
@@ -289,89 +291,50 @@ struct S2PairArgs {
     const uint32_t *X, *Z, *S;       // Q, s
     const uint32_t *PbX;             // normalised baby steps
     const uint32_t *PdX, *PdZ;       // Pd = [D]Q
-    uint32_t *PaX, *PaZ, *PaI;       // giant-step ring, 2L entries each: X, Z, X/Z
-    uint32_t *bp;                    // scratch for prefix products, 2L entries
+    uint32_t *gx, *gz;               // chunk scratch: X, Z of the giant steps being generated, G+2 entries
+                                     // (entries 0,1 = the last two steps of the previous chunk)
+    uint32_t *gp;                    // prefix products, G entries
+    uint32_t *ring;                  // X/Z of the giant steps, ring of `ring_size` entries (power of two)
     uint32_t *acc;                   // in/out accumulator
     uint32_t *fail;
-    const uint32_t *steps;           // pair tape: (pa << 16 | 0xffff-marked) see host; 2 words per step
-    uint32_t nsteps, U, L, D;
-    uint64_t A0;                     // 2*amin*D   ecm.c:2378
+    const uint32_t *steps;           // pair tape, 2 words per step (see S2_STEP_GEN)
+    uint32_t nsteps, D, G, ring_size;
+    uint64_t A0;                     // multiplier of the first giant step: 2*amin*D   ecm.c:2378
     size_t stride;
 };
 
-#define S2_STEP_SHIFT 0xffffffffu
+// tape word 0 == S2_STEP_GEN: generate the next `word 1` giant steps (continuing the sequence) and
+// normalise them into the ring.  Otherwise (slot, pb): acc *= ring[slot] - PbX[pb].
+#define S2_STEP_GEN 0xffffffffu
 
-// normalise ring slots [first, first+n) (window positions): PaI = PaX / PaZ
+// Giant steps.  The reference keeps a window of 2L = 4U steps and, at every window shift, makes 2U new
+// ones and inverts them (ecm.c:2458-2502): 1,341 inversions at B2 = 1e8.  Here they are produced in
+// chunks of G >> 2U steps with ONE inversion per chunk; the ring holds the normalised X/Z of every
+// step a pair can still ask for.  Same points, same (unique) inverses, same accumulator.
 template <int NL>
-__device__ __forceinline__ void ring_normalise(const S2PairArgs &a, uint32_t w0, uint32_t first, uint32_t n,
-                                               const S2Const<NL> &k, uint32_t idx)
+__device__ __forceinline__ void giant_chunk(const S2PairArgs &a, uint32_t first_abs, uint32_t n, bool very_first,
+                                            const S2Const<NL> &k, uint32_t idx)
 {
-    const size_t stride = a.stride;
-    const uint32_t ring = 2 * a.L;
-    Fe<NL> acc, z, x, t;
-    tb_load(acc, a.PaZ, stride, idx, (w0 + first) % ring);
-    tb_store(a.bp, stride, idx, 0, acc);
-    for (uint32_t i = 1; i < n; i++) {
-        tb_load(z, a.PaZ, stride, idx, (w0 + first + i) % ring);
-        fe_mul(acc, acc, z, k.m);
-        tb_store(a.bp, stride, idx, i, acc);
-    }
-    Fe<NL> inv;
-    fe_inv_mont(inv, acc, k, a.fail, stride, idx);
-    for (uint32_t i = n - 1; i > 0; i--) {
-        uint32_t slot = (w0 + first + i) % ring;
-        tb_load(t, a.bp, stride, idx, i - 1);
-        fe_mul(t, t, inv, k.m);
-        tb_load(z, a.PaZ, stride, idx, slot);
-        fe_mul(inv, inv, z, k.m);
-        tb_load(x, a.PaX, stride, idx, slot);
-        fe_mul(x, x, t, k.m);
-        tb_store(a.PaI, stride, idx, slot, x);
-    }
-    uint32_t slot = (w0 + first) % ring;
-    tb_load(x, a.PaX, stride, idx, slot);
-    fe_mul(x, x, inv, k.m);
-    tb_store(a.PaI, stride, idx, slot, x);
-}
-
-// Pa[pos] = Pa[pos-1] + Pd, difference Pa[pos-2]   (ecm.c:2412-2416, 2473-2476)
-template <int NL>
-__device__ __forceinline__ void ring_step(const S2PairArgs &a, uint32_t w0, uint32_t pos, const Fe<NL> &sD, const Fe<NL> &dD,
-                                          const ModK<NL> &m, uint32_t idx)
-{
-    const size_t stride = a.stride;
-    const uint32_t ring = 2 * a.L;
-    Pt<NL> p1, p2, T;
-    Fe<NL> s1, d1, pp, mm;
-    uint32_t s_1 = (w0 + pos + ring - 1) % ring, s_2 = (w0 + pos + ring - 2) % ring, s_0 = (w0 + pos) % ring;
-    tb_load(p1.X, a.PaX, stride, idx, s_1);
-    tb_load(p1.Z, a.PaZ, stride, idx, s_1);
-    pt_sumdiff(s1, d1, p1, m);
-    pt_add_uv(pp, mm, s1, d1, sD, dD, m);
-    tb_load(p2.X, a.PaX, stride, idx, s_2);
-    tb_load(p2.Z, a.PaZ, stride, idx, s_2);
-    fe_mul(T.X, pp, p2.Z, m);
-    fe_mul(T.Z, mm, p2.X, m);
-    tb_store(a.PaX, stride, idx, s_0, T.X);
-    tb_store(a.PaZ, stride, idx, s_0, T.Z);
-}
-
-// ecm_stage2_pair, ecm.c:2342-2540
-template <int NL>
-__device__ __forceinline__ void s2_pair(const S2PairArgs &a, const S2Const<NL> &k, uint32_t idx)
-{
+    // its own kernel launch (k_s2_gen, ~84 per curve batch at B2=1e8): everything it needs is read from
+    // memory, so the pair-walk kernel keeps only the accumulator and two operand pairs live
     const ModK<NL> &m = k.m;
     const size_t stride = a.stride;
-    const uint32_t ring = 2 * a.L;
     Pt<NL> Q, Pd;
     Fe<NL> s4, sD, dD;
-    fe_load(Q.X, a.X, stride, idx);
-    fe_load(Q.Z, a.Z, stride, idx);
-    fe_load(s4, a.S, stride, idx);
     fe_load(Pd.X, a.PdX, stride, idx);
     fe_load(Pd.Z, a.PdZ, stride, idx);
     pt_sumdiff(sD, dD, Pd, m);
-    {
+    if (very_first) {
+        fe_load(Q.X, a.X, stride, idx);
+        fe_load(Q.Z, a.Z, stride, idx);
+        fe_load(s4, a.S, stride, idx);
+    }
+    // The two most recent giant steps stay in registers across the loop (p1 = latest, p2 = the one
+    // before); the scratch arrays only receive stores here, so no step waits on a store->load round
+    // trip.  Scratch slot i+2 holds chunk entry i; slots 0,1 hold the two steps before the chunk.
+    uint32_t start = 0;
+    Pt<NL> p1, p2;
+    if (very_first) {
         Pt<NL> P0 = Q, Pad = Q, T;
         pt_ladder(P0, a.A0, s4, m);                   // Pa[0] = [A]Q      ecm.c:2380-2383
         pt_ladder(Pad, a.A0 - a.D, s4, m);            // Pad = [A-D]Q     ecm.c:2388-2390
@@ -380,29 +343,89 @@ __device__ __forceinline__ void s2_pair(const S2PairArgs &a, const S2Const<NL> &
         pt_add_uv(pp, mm, s1, d1, sD, dD, m);
         fe_mul(T.X, pp, Pad.Z, m);                    // Pa[1] = Pa[0] + Pd (Pad)   ecm.c:2395-2401
         fe_mul(T.Z, mm, Pad.X, m);
-        tb_store(a.PaX, stride, idx, 0, P0.X); tb_store(a.PaZ, stride, idx, 0, P0.Z);
-        tb_store(a.PaX, stride, idx, 1, T.X);  tb_store(a.PaZ, stride, idx, 1, T.Z);
+        tb_store(a.gx, stride, idx, 2, P0.X); tb_store(a.gz, stride, idx, 2, P0.Z);
+        tb_store(a.gx, stride, idx, 3, T.X);  tb_store(a.gz, stride, idx, 3, T.Z);
+        p2 = P0;
+        p1 = T;
+        start = 2;
+    } else {
+        tb_load(p2.X, a.gx, stride, idx, 0); tb_load(p2.Z, a.gz, stride, idx, 0);
+        tb_load(p1.X, a.gx, stride, idx, 1); tb_load(p1.Z, a.gz, stride, idx, 1);
     }
-    uint32_t w0 = 0;
-    for (uint32_t i = 2; i < ring; i++) ring_step<NL>(a, w0, i, sD, dD, m, idx);   // ecm.c:2408-2424
-    ring_normalise<NL>(a, w0, 0, ring, k, idx);                                      // ecm.c:2428
+    for (uint32_t i = start; i < n; i++) {            // Pa[i] = Pa[i-1] + Pd, difference Pa[i-2]  ecm.c:2412-2416
+        Pt<NL> T;
+        Fe<NL> s1, d1, pp, mm;
+        pt_sumdiff(s1, d1, p1, m);
+        pt_add_uv(pp, mm, s1, d1, sD, dD, m);
+        fe_mul(T.X, pp, p2.Z, m);
+        fe_mul(T.Z, mm, p2.X, m);
+        tb_store(a.gx, stride, idx, i + 2, T.X);
+        tb_store(a.gz, stride, idx, i + 2, T.Z);
+        p2 = p1;
+        p1 = T;
+    }
+    // the last two steps seed the next chunk
+    tb_store(a.gx, stride, idx, 0, p2.X); tb_store(a.gz, stride, idx, 0, p2.Z);
+    tb_store(a.gx, stride, idx, 1, p1.X); tb_store(a.gz, stride, idx, 1, p1.Z);
+    // Montgomery's trick over the chunk (ecm.c:2003-2136), results into the ring
+    Fe<NL> acc, z, x, t;
+    tb_load(acc, a.gz, stride, idx, 2);
+    tb_store(a.gp, stride, idx, 0, acc);
+    for (uint32_t i = 1; i < n; i++) {
+        tb_load(z, a.gz, stride, idx, i + 2);
+        fe_mul(acc, acc, z, m);
+        tb_store(a.gp, stride, idx, i, acc);
+    }
+    Fe<NL> inv;
+    fe_inv_mont(inv, acc, k, a.fail, stride, idx);
+    const uint32_t rmask = a.ring_size - 1;
+    for (uint32_t i = n - 1; i > 0; i--) {
+        tb_load(t, a.gp, stride, idx, i - 1);
+        fe_mul(t, t, inv, m);
+        tb_load(z, a.gz, stride, idx, i + 2);
+        fe_mul(inv, inv, z, m);
+        tb_load(x, a.gx, stride, idx, i + 2);
+        fe_mul(x, x, t, m);
+        tb_store(a.ring, stride, idx, (first_abs + i) & rmask, x);
+    }
+    tb_load(x, a.gx, stride, idx, 2);
+    fe_mul(x, x, inv, m);
+    tb_store(a.ring, stride, idx, first_abs & rmask, x);
+}
+
+// The pair walk of ecm_stage2_pair (ecm.c:2448-2533) over tape entries [first, first+count): every
+// entry is a pair (ring slot, table index); "generate" marks are separate launches of giant_chunk.
+template <int NL>
+__device__ __forceinline__ void s2_pairs(const S2PairArgs &a, uint32_t first, uint32_t count, const S2Const<NL> &k,
+                                         uint32_t idx)
+{
+    const ModK<NL> &m = k.m;
+    const size_t stride = a.stride;
+    if (count == 0) return;
     Fe<NL> acc;
     fe_load(acc, a.acc, stride, idx);
-    for (uint32_t sidx = 0; sidx < a.nsteps; sidx++) {
-        uint32_t pa = a.steps[2 * sidx], pb = a.steps[2 * sidx + 1];
-        pa = __builtin_amdgcn_readfirstlane(pa);
-        pb = __builtin_amdgcn_readfirstlane(pb);
-        if (pa == S2_STEP_SHIFT) {                    // window shift by 2U  ecm.c:2458-2502
-            uint32_t sh = 2 * a.U;
-            w0 = (w0 + sh) % ring;
-            for (uint32_t i = ring - sh; i < ring; i++) ring_step<NL>(a, w0, i, sD, dD, m, idx);
-            ring_normalise<NL>(a, w0, ring - sh, sh, k, idx);
-        } else {                                      // CROSS_PRODUCT_INV  ecm.c:1857-1859
-            Fe<NL> x, y, t;
-            tb_load(x, a.PaI, stride, idx, (w0 + pa) % ring);
-            tb_load(y, a.PbX, stride, idx, pb);
-            fe_sub(t, x, y, m);
-            fe_mul(acc, acc, t, m);
+    // One-step lookahead: the two table rows of the NEXT pair are requested before the multiply of the
+    // current one, so their HBM latency (the ring and the 461-KB-per-curve baby-step table do not stay
+    // in cache) hides behind ~2k cycles of arithmetic.
+    const uint32_t *st = a.steps + 2 * (size_t)first;
+    Fe<NL> x, y, xn, yn;
+    uint32_t w0 = __builtin_amdgcn_readfirstlane(st[0]), w1 = __builtin_amdgcn_readfirstlane(st[1]);
+    tb_load(x, a.ring, stride, idx, w0);
+    tb_load(y, a.PbX, stride, idx, w1);
+    for (uint32_t i = 0; i < count; i++) {
+        const bool more = i + 1 < count;
+        if (more) {
+            w0 = __builtin_amdgcn_readfirstlane(st[2 * i + 2]);
+            w1 = __builtin_amdgcn_readfirstlane(st[2 * i + 3]);
+            tb_load(xn, a.ring, stride, idx, w0);
+            tb_load(yn, a.PbX, stride, idx, w1);
+        }
+        Fe<NL> t;
+        fe_sub(t, x, y, m);                           // CROSS_PRODUCT_INV  ecm.c:1857-1859
+        fe_mul(acc, acc, t, m);
+        if (more) {
+            x = xn;
+            y = yn;
         }
     }
     Fe<NL> c;

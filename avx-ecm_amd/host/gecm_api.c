@@ -563,6 +563,9 @@ int gecm_stage1_factor(gecm_ctx *c, size_t k, char *dec, size_t declen, int *is_
 }
 
 /* ---- stage 2 -------------------------------------------------------------------------------- */
+/* giant steps per device chunk (one inversion each) and ring size (power of two >= chunk + 2L) */
+#define S2_GIANT_CHUNK 512u
+#define S2_RING 1024u
 /* point additions next_pt_vec performs for multiplier c (one per bit below the top one, ecm.c:939-966) */
 static uint64_t ladder_adds(uint64_t c)
 {
@@ -584,9 +587,9 @@ int gecm_stage2_init(gecm_ctx *c, uint32_t D, uint32_t U)
     c->have_acc = 0;
     c->s2_ptadds = (uint64_t)c->s2.umax - 2 + ladder_adds(D);   /* ecm.c:2263: j = 3..U*w; Pd ladder :2334 */
     c->s2_numinv = 1;                                        /* ecm.c:2322 */
-    c->s2_devinv = (c->s2.npb - 1 + 31) / 32;
+    c->s2_devinv = (c->s2.npb - 1 + GECM_S2_BLK - 1) / GECM_S2_BLK;
     c->s2_paired = 0;
-    if (gecm_dev_s2_init(c->dev, c->s2.keep, c->s2.keep_words, c->s2.umax, D, c->s2.npb, c->s2.L)) {
+    if (gecm_dev_s2_init(c->dev, c->s2.keep, c->s2.keep_words, c->s2.umax, D, c->s2.npb, S2_GIANT_CHUNK, S2_RING)) {
         set_err("gecm_stage2_init: %s", gecm_dev_error());
         return GECM_ERR_DEVICE;
     }
@@ -617,17 +620,28 @@ int gecm_stage2_pair(gecm_ctx *c, uint32_t steps, const uint32_t *pm_v, const ui
     if (!c || !c->s2_ready) { set_err("gecm_stage2_pair: gecm_stage2_init has not run"); return GECM_ERR_STATE; }
     if (steps && (!pm_v || !pm_u)) return GECM_ERR_ARG;
     const gecm_s2_plan *p = &c->s2;
-    /* resolve the map on the host: window index pa = v - amin (ecm.c:2505), table index map[u] */
-    uint32_t *tape = (uint32_t *)malloc(((size_t)steps * 2 + 2) * sizeof(uint32_t));
+    /* Resolve the map on the host.  A pair (v,u) refers to giant step number 2*amin_now + (v - amin_now)
+     * counted from [A0]Q in steps of D (ecm.c:2378, 2505) and to table entry map[u].  The device makes
+     * giant steps in chunks of S2_GIANT_CHUNK (one inversion each, csrc/gecm_stage2.hpp) into a ring, so
+     * the tape carries ring slots and "generate n more" marks; the reference's counters (one batch
+     * of 2U new steps and one inversion per window shift) are kept for the statistics. */
+    uint32_t *tape = (uint32_t *)malloc(((size_t)steps * 2 + 2 * ((size_t)steps / 16 + 64)) * sizeof(uint32_t));
     if (!tape) return GECM_ERR_NOMEM;
+    size_t nt = 0;
     uint32_t run_amin = amin;
-    uint64_t adds = 2ull * p->L - 1, inv = 2, paired = 0, devinv = 1;   /* ecm.c:2401-2429 */
+    uint64_t adds = 2ull * p->L - 1, inv = 2, paired = 0, devinv = 0;   /* ecm.c:2401-2429 */
+    uint64_t generated = 0;                      /* giant steps the device will have made so far */
+    const uint64_t base = 2ull * amin;           /* absolute number of giant step 0 (in units of D) */
+#define NEED(upto)                                                                                   \
+    while (generated < (upto)) {                                                                     \
+        tape[nt++] = 0xffffffffu; tape[nt++] = S2_GIANT_CHUNK; generated += S2_GIANT_CHUNK; devinv++; \
+    }
+    NEED(2ull * p->L);
     for (uint32_t i = 0; i < steps; i++) {
         if (pm_v[i] == 0 && pm_u[i] == 0) {
-            tape[2 * i] = 0xffffffffu;
-            tape[2 * i + 1] = 0;
             run_amin += p->U;                                            /* ecm.c:2496 */
-            adds += 2ull * p->U; inv++; devinv++;
+            adds += 2ull * p->U; inv++;
+            NEED(2ull * run_amin - base + 2ull * p->L);
         } else {
             uint32_t pa = pm_v[i] - run_amin, pb = pm_u[i];
             if (pa >= 2 * p->L || pb > p->umax || p->map[pb] == 0) {     /* ecm.c:2508-2517 */
@@ -635,14 +649,16 @@ int gecm_stage2_pair(gecm_ctx *c, uint32_t steps, const uint32_t *pm_v, const ui
                 set_err("gecm_stage2_pair: invalid pair map entry %u: (%u,%u) amin %u", i, pm_v[i], pm_u[i], run_amin);
                 return GECM_ERR_ARG;
             }
-            tape[2 * i] = pa;
-            tape[2 * i + 1] = p->map[pb];
+            uint64_t absidx = 2ull * run_amin - base + pa;
+            tape[nt++] = (uint32_t)(absidx & (S2_RING - 1));
+            tape[nt++] = p->map[pb];
             paired++;
         }
     }
+#undef NEED
     uint64_t A0 = (uint64_t)amin * p->D * 2;                             /* ecm.c:2378 */
     adds += ladder_adds(A0) + ladder_adds(A0 - p->D);                    /* ecm.c:2383, 2390 */
-    int rc = gecm_dev_s2_pair(c->dev, tape, steps, p->U, p->L, p->D, A0);
+    int rc = gecm_dev_s2_pair(c->dev, tape, (uint32_t)(nt / 2), p->D, S2_GIANT_CHUNK, S2_RING, A0);
     free(tape);
     if (rc) { set_err("gecm_stage2_pair: %s", gecm_dev_error()); return GECM_ERR_DEVICE; }
     c->s2_ptadds += adds; c->s2_numinv += inv; c->s2_paired += paired; c->s2_devinv += devinv;

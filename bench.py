@@ -113,6 +113,7 @@ def main():
     ap.add_argument("--b1", type=int, default=1000000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-small-batch", action="store_true")
+    ap.add_argument("--b2", type=int, default=0, help="also time one stage-2 pass to this B2 (reported separately)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -170,6 +171,17 @@ def main():
 
     st = eng.stage1_stats()
     cfg = eng.cfg
+    stage2 = None
+    if a.b2 > a.b1:
+        # not part of the metric: one pass of the stage-2 continuation on the resident batch
+        t2 = time.perf_counter()
+        eng.stage2(a.b2)
+        nf2, _ = eng.scan_factors(2)
+        t2 = time.perf_counter() - t2
+        s2 = eng.stage2_stats()
+        stage2 = {"B2": a.b2, "seconds": t2, "curves_per_s": a.curves / t2, "D": s2.D, "U": s2.U,
+                  "ptadds": s2.ptadds, "inversions": s2.numinv, "pair_muls": s2.paired,
+                  "curves_with_factor": nf2}
     small = None
     if world == 1 and a.curves != 4096 and not a.no_small_batch:
         # BASELINE.json configs[1] names a 4096-curve batch: 64 wavefronts, 3% of the 2048 resident
@@ -225,6 +237,8 @@ def main():
         }
         if small:
             line["batch_4096"] = small
+        if stage2:
+            line["stage2"] = stage2
         if not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(n, a.b1)
         print(json.dumps(line), flush=True)

