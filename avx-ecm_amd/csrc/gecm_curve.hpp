@@ -79,6 +79,55 @@ __device__ __forceinline__ void pt_add_uv(Fe<NL> &pp, Fe<NL> &mm, const Fe<NL> &
     fe_sqr(mm, mm, m);      // (U-V)^2
 }
 
+// Where the third PRAC point C lives.  Up to NL = 19 all of A, B, C fit in the 256 VGPRs that
+// 2 waves/SIMD allow.  Above that C is parked in LDS, [coord][limb][lane] (conflict-free: lane l hits
+// bank l): C is only read for the last two multiplies of an addition and written once per step, and a
+// wave's 2*NL*256 bytes (15 KB at NL=30) leave room for the 8 waves of a CU in the 160 KB.
+template <int NL, bool IN_LDS>
+struct CStore;
+
+template <int NL>
+struct CStore<NL, false> {
+    Pt<NL> c;
+    __device__ __forceinline__ void put(const Pt<NL> &p) { c = p; }
+    __device__ __forceinline__ void get(Pt<NL> &p) const { p = c; }
+    __device__ __forceinline__ void getX(Fe<NL> &x) const { x = c.X; }
+    __device__ __forceinline__ void getZ(Fe<NL> &z) const { z = c.Z; }
+};
+
+template <int NL>
+struct CStore<NL, true> {
+    uint32_t *lds;   // this lane's column: word (coord*NL + limb)*64
+    __device__ __forceinline__ void put(const Pt<NL> &p)
+    {
+#pragma unroll
+        for (int i = 0; i < NL; i++) {
+            lds[i * 64] = p.X.v[i];
+            lds[(NL + i) * 64] = p.Z.v[i];
+        }
+    }
+    __device__ __forceinline__ void getX(Fe<NL> &x) const
+    {
+#pragma unroll
+        for (int i = 0; i < NL; i++) x.v[i] = lds[i * 64];
+    }
+    __device__ __forceinline__ void getZ(Fe<NL> &z) const
+    {
+#pragma unroll
+        for (int i = 0; i < NL; i++) z.v[i] = lds[(NL + i) * 64];
+    }
+    __device__ __forceinline__ void get(Pt<NL> &p) const
+    {
+        getX(p.X);
+        getZ(p.Z);
+    }
+};
+
+template <int NL>
+struct TapePolicy {
+    static constexpr bool c_in_lds = (NL > 19);
+};
+
 // Run a tape on point P (held in A).  Returns with the result in A.
 //
 // The loop body contains exactly ONE inlined point addition and ONE inlined doubling (~55 KB of
@@ -90,9 +139,10 @@ __device__ __forceinline__ void pt_add_uv(Fe<NL> &pp, Fe<NL> &mm, const Fe<NL> &
 template <int NL>
 __device__ __forceinline__ void run_tape(const uint32_t *__restrict__ tape, uint32_t tape_len, Pt<NL> &A,
                                          const uint32_t *__restrict__ S, size_t stride, uint32_t idx,
-                                         const ModK<NL> &m)
+                                         const ModK<NL> &m, CStore<NL, TapePolicy<NL>::c_in_lds> &cst)
 {
-    Pt<NL> B = A, C = A;
+    Pt<NL> B = A;
+    cst.put(A);
     auto fetch = [&](uint32_t pc) -> uint32_t {
         // one tape byte; past the end reads as NOP (the host pads the tape with zero words)
         uint32_t w = tape[pc >> 2];
@@ -120,9 +170,17 @@ __device__ __forceinline__ void run_tape(const uint32_t *__restrict__ tape, uint
             pt_sumdiff(s2, d2, A, m);
             pt_add_uv(pp, mm, s1, d1, s2, d2, m);
             Pt<NL> T;
-            fe_mul(T.X, pp, C.Z, m);
-            fe_mul(T.Z, mm, C.X, m);
-            C = B;
+            {
+                Fe<NL> cz;
+                cst.getZ(cz);
+                fe_mul(T.X, pp, cz, m);
+            }
+            {
+                Fe<NL> cx;
+                cst.getX(cx);
+                fe_mul(T.Z, mm, cx, m);
+            }
+            cst.put(B);
             B = T;
             pc++;
             op = nxt;
@@ -139,6 +197,8 @@ __device__ __forceinline__ void run_tape(const uint32_t *__restrict__ tape, uint
         const bool is_step = op >= GECM_OP_STEP;
         const bool do_add = op != GECM_OP_PRAC_BEGIN;
         const bool do_dup = op != GECM_OP_PRAC_END;
+        Pt<NL> C;
+        cst.get(C);
         if (is_step && (op & GECM_OP_SWAP)) {       // ecm.c:617-630
             Pt<NL> t = A;
             A = B;
@@ -192,5 +252,6 @@ __device__ __forceinline__ void run_tape(const uint32_t *__restrict__ tape, uint
             B = D;
             A = oldA;
         }
+        cst.put(C);
     }
 }

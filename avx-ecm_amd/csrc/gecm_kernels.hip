@@ -28,7 +28,11 @@ k_stage1(const uint32_t *__restrict__ tape, uint32_t tape_len, uint32_t *__restr
     Pt<NL> P;
     fe_load(P.X, X, stride, idx);
     fe_load(P.Z, Z, stride, idx);
-    run_tape<NL>(tape, tape_len, P, S, stride, idx, a.m);
+    constexpr bool CL = TapePolicy<NL>::c_in_lds;
+    __shared__ uint32_t lds_c[CL ? 2 * NL * 64 : 1];
+    CStore<NL, CL> cst;
+    if constexpr (CL) cst.lds = lds_c + threadIdx.x;
+    run_tape<NL>(tape, tape_len, P, S, stride, idx, a.m, cst);
     Fe<NL> ox, oz;
     fe_canonical_mont(ox, P.X, a.one, a.m);
     fe_canonical_mont(oz, P.Z, a.one, a.m);
