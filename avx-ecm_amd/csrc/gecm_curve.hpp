@@ -123,9 +123,12 @@ struct CStore<NL, true> {
     }
 };
 
+#ifndef GECM_C_LDS_ABOVE
+#define GECM_C_LDS_ABOVE 19
+#endif
 template <int NL>
 struct TapePolicy {
-    static constexpr bool c_in_lds = (NL > 19);
+    static constexpr bool c_in_lds = (NL > GECM_C_LDS_ABOVE);
 };
 
 // Run a tape on point P (held in A).  Returns with the result in A.

@@ -174,3 +174,14 @@ def test_mpl_bigint_kit(lib):
         assert buf.value.decode() == str(a)
         lib.mpl_get_hex(buf, ctypes.byref(A))
         assert buf.value.decode() == "%x" % a
+
+
+def test_cli_without_gpu_fails_loudly():
+    import pyecm
+    if pyecm.device_count() > 0:
+        pytest.skip("a GPU is present")
+    exe = os.path.join(ROOT, "avx-ecm_amd", "avx-ecm")
+    p = subprocess.run([exe, "1000003*1000033", "8", "1000", "1", "1000", "7"], capture_output=True, text=True)
+    assert p.returncode == 2 and "no HIP device" in p.stderr
+    p = subprocess.run([exe, "2^64", "8", "1000"], capture_output=True, text=True)       # even input
+    assert p.returncode == 1 and "odd integer" in p.stdout
