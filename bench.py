@@ -113,6 +113,8 @@ def main():
     ap.add_argument("--b1", type=int, default=1000000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-small-batch", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; "
+                    "gloo only to rehearse the multi-rank control flow on fewer GPUs than ranks)")
     ap.add_argument("--b2", type=int, default=0, help="also time one stage-2 pass to this B2 (reported separately)")
     a = ap.parse_args()
 
@@ -121,21 +123,26 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     dist = None
+    import pyecm
+    ndev = max(1, pyecm.device_count())
+    devno = local_rank % ndev
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    import pyecm
+        if a.backend == "nccl":
+            torch.cuda.set_device(devno)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", devno))
+        else:
+            dist.init_process_group(backend=a.backend)
 
     from pyecm import shard
     n = random.Random(a.bits).getrandbits(a.bits) | (1 << (a.bits - 1)) | 1
-    eng = pyecm.Engine(n, digitbits=52, device=local_rank)
+    eng = pyecm.Engine(n, digitbits=52, device=devno)
     # host-side split of the curve batch (pyecm/shard.py): rank g owns the contiguous global curve
     # indices [g*C, (g+1)*C), sigma = 1000 + index
     total = a.curves * world
     lo, hi = shard.shard_bounds(total, rank, world)
     eng.build_curves(shard.shard_sigmas(1000, total, rank, world))
-    dev = "cuda:%d" % local_rank
+    dev = "cuda:%d" % devno if (world == 1 or a.backend == "nccl") else "cpu"
 
     def barrier():
         if dist is not None:
@@ -165,7 +172,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda:%d" % local_rank)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 

@@ -1,0 +1,71 @@
+"""Error behaviour of the C ABI on a GPU box: misuse returns negative codes with a message, never a
+crash, never a silent fallback (the reference printf+exit()s: util.c:56-59, ecm.c:969-970)."""
+import ctypes
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_argument_and_state_errors():
+    import pyecm
+    L = pyecm.lib
+    n = (1 << 127) - 1
+    eng = pyecm.Engine(n * ((1 << 89) - 1))
+    with pytest.raises(pyecm.GecmError, match="no curves"):
+        eng.stage1(1000)                                   # nothing uploaded
+    arr = (ctypes.c_uint64 * 1)(1000)
+    assert L.gecm_build_curves(eng._h, arr, 0) == -2       # empty batch
+    with pytest.raises(pyecm.GecmError, match="sigma"):
+        eng.build_curves([5])                              # ecm.c:1564-1570: sigma >= 6
+    eng.build_curves([6, 7, 8])
+    with pytest.raises(pyecm.GecmError):
+        eng.stage1(1)                                      # B1 < 2
+    with pytest.raises(pyecm.GecmError):
+        eng.stage1(10 ** 9)                                # more than one prime range
+    with pytest.raises(pyecm.GecmError, match="stage 1"):
+        eng.stage2_init()                                  # stage 2 before stage 1
+    eng.stage1(100)
+    with pytest.raises(pyecm.GecmError):
+        eng.stage2(50)                                     # B2 <= B1
+    with pytest.raises(pyecm.GecmError, match="gecm_stage2_init has not run"):
+        pm = pyecm.pair_primes(100, 5000, 210, 2)
+        eng.stage2_pair(pm)
+    eng.stage2_init(210, 2)
+    bad_v = (ctypes.c_uint32 * 1)(10 ** 6)
+    bad_u = (ctypes.c_uint32 * 1)(1)
+    assert L.gecm_stage2_pair(eng._h, 1, bad_v, bad_u, 1) == -2   # pair outside the window (ecm.c:2508-2511)
+    assert b"invalid pair map entry" in L.gecm_last_error()
+    eng.close()
+
+
+def test_unsupported_sizes_and_inputs():
+    import pyecm
+    with pytest.raises(pyecm.GecmError, match="larger than this build supports"):
+        pyecm.Engine((1 << 1100) + 1)
+    with pytest.raises(pyecm.GecmError, match="odd"):
+        pyecm.Engine(1 << 100)
+    with pytest.raises(pyecm.GecmError):
+        pyecm.Engine(12345678901234567891, digitbits=40)
+    # largest supported class: 1031 bits (37 limbs of 28 bits, R >= 32 N)
+    e = pyecm.Engine((1 << 1030) + 1)
+    assert e.cfg.dev_limbs == 37
+    e.close()
+
+
+def test_tiny_bounds_and_b1_change():
+    """B1 = 2, 3, 4 (empty / one-doubling tapes) and changing B1 on a live context"""
+    import pyecm
+    n = ((1 << 127) - 1) * ((1 << 107) - 1)
+    eng = pyecm.Engine(n)
+    eng.build_curves([11, 12])
+    eng.stage1(2)
+    x0, z0 = eng.download_points_plain()
+    assert z0 == [1, 1]                                    # empty tape: Z still 1
+    st = eng.stage1_stats()
+    assert (st.ptadds, st.ptdups, st.tape_len) == (0, 0, 0)
+    eng.stage1(3)
+    assert (eng.stage1_stats().ptdups, eng.stage1_stats().ptadds) == (1, 0)
+    eng.stage1(1000)
+    assert eng.stage1_stats().ptadds == 1796
+    eng.close()
