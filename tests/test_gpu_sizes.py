@@ -111,3 +111,42 @@ def test_upload_points_roundtrip_and_reference_radix():
     x, z = eng.download_points_plain()
     assert x == xs and z == zs
     eng.close()
+
+
+ADVERSARIAL = [
+    # K = 2^k N is the subtraction bias; these moduli put it at the two ends of its range [R/32, R/16)
+    # and make every limb of N (hence every q*N product) maximal or minimal.
+    ("2^415-1", (1 << 415) - 1),            # all-ones limbs, K just below R/16   (NL=15)
+    ("2^414+1", (1 << 414) + 1),            # K just above R/32
+    ("2^387+2^200+1", (1 << 387) + (1 << 200) + 1),   # smallest size that still needs NL=15
+    ("2^639-1", (1 << 639) - 1),            # NL=23, the largest count without sub renormalisation
+    ("2^723-1", (1 << 723) - 1),            # NL=26, the smallest count with it
+    ("2^835-1", (1 << 835) - 1),            # NL=30, all-ones
+    ("2^1031-1", (1 << 1031) - 1),          # NL=37, all-ones, largest supported size
+]
+
+
+@pytest.mark.parametrize("name,n", ADVERSARIAL, ids=[a[0] for a in ADVERSARIAL])
+def test_extreme_moduli_against_oracle(orc, name, n):
+    """lazy-reduction bounds (csrc/gecm_field.hpp) at their extremes: residues after 2,000+ point
+    operations still equal the oracle's canonical ones"""
+    import pyecm
+    rng = random.Random(len(name))
+    sig = [rng.randrange(6, 1 << 64) for _ in range(64)]
+    eng = pyecm.Engine(n)
+    eng.build_curves(sig)
+    eng.stage1(1500)
+    lines = eng.save_lines()
+    R = 1 << eng.cfg.maxbits
+    Ri = pow(R, -1, n)
+    a = [n - 1, n - 1, 1, (n + 1) // 2, n - 2] + [rng.randrange(n) for _ in range(59)]
+    b = [n - 1, 1, n - 1, (n - 1) // 2, n - 2] + [rng.randrange(n) for _ in range(59)]
+    assert eng.vecmulmod(a, b) == [x * y * Ri % n for x, y in zip(a, b)]
+    assert eng.vecsubmod(a, b) == [(x - y) % n for x, y in zip(a, b)]
+    eng.close()
+    c = orc.orc_create(str(n).encode(), 52)
+    line = ctypes.create_string_buffer(16384)
+    for k in range(0, 64, 7):
+        orc.orc_stage1_line(c, sig[k], 1500, line, len(line), None, 0, None)
+        assert line.value.decode() == lines[k], (name, sig[k])
+    orc.orc_destroy(c)
