@@ -11,10 +11,12 @@
 #include "gecm_plan.h"
 #include "gecm_pair.h"
 #include "mpl.h"
+#include <pthread.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #define LIMB_BITS 28
 
@@ -60,6 +62,8 @@ struct gecm_ctx {
     uint32_t *hacc, *hfail;
     int have_acc;
     uint32_t *flags[2];      /* per-curve result of the last device factor scan: stage 1, stage 2 */
+    uint32_t *hg[2];         /* and the gcds it computed, [nl][batch] */
+    int scan_valid[2];       /* the cached scan belongs to the current stage-1 / stage-2 result */
     uint64_t s2_ptadds, s2_numinv, s2_paired, s2_devinv;
     uint32_t s2_amin_last;
 };
@@ -169,8 +173,10 @@ int gecm_create(gecm_ctx **out, int device, const char *n_str, int digitbits)
 static void free_batch(gecm_ctx *c)
 {
     free(c->sigma); free(c->bad); free(c->hx); free(c->hz); free(c->hacc); free(c->hfail);
-    free(c->flags[0]); free(c->flags[1]);
+    free(c->flags[0]); free(c->flags[1]); free(c->hg[0]); free(c->hg[1]);
     c->flags[0] = c->flags[1] = NULL;
+    c->hg[0] = c->hg[1] = NULL;
+    c->scan_valid[0] = c->scan_valid[1] = 0;
     c->sigma = NULL; c->bad = NULL; c->hx = c->hz = NULL; c->hacc = c->hfail = NULL;
     c->have_acc = 0; c->s2_ready = 0;
     c->batch = 0;
@@ -339,31 +345,34 @@ static void suyama_pre(const mpl_t *n, uint64_t sigma, mpl_t *x3, mpl_t *z3, mpl
     mpl_mod(den, &t2, n);               /* 16 u^3 v               ecm.c:1718-1720 */
 }
 
-int gecm_build_curves(gecm_ctx *c, const uint64_t *sigma, size_t batch)
+/* One worker's slice [lo, hi) of the batch: the whole Suyama construction for those curves.
+ * The two inversions per curve, mpz_invert(16u^3v) ecm.c:1745 and mpz_invert(v^3) ecm.c:1759, share the
+ * modulus, so each slice does Montgomery's simultaneous inversion: one extended Euclid per slice
+ * instead of two per curve.  Inverses mod N are unique, so the values are the ones GMP returns. */
+typedef struct {
+    gecm_ctx *c;
+    const uint64_t *sigma;
+    size_t batch, lo, hi;
+    uint32_t *hX, *hZ, *hS;
+    int anybad, rc;
+} build_job;
+
+static void *build_slice(void *arg)
 {
-    if (!c || !sigma || batch == 0) { set_err("gecm_build_curves: bad argument"); return GECM_ERR_ARG; }
-    int rc = alloc_batch(c, batch);
-    if (rc) return rc;
-    for (size_t i = 0; i < batch; i++) {
-        if (sigma[i] < 6) { set_err("gecm_build_curves: sigma[%zu] < 6", i); return GECM_ERR_ARG; }
-        c->sigma[i] = sigma[i];
-    }
-    int nl = c->nl, anybad = 0;
-    size_t words = (size_t)nl * batch;
-    uint32_t *hX = (uint32_t *)calloc(words * 3, 4);
-    mpl_t *x3 = (mpl_t *)malloc(batch * sizeof(mpl_t) * 2);
-    mpl_t *dens = (mpl_t *)malloc(batch * 2 * sizeof(mpl_t));
-    mpl_t *pref = (mpl_t *)malloc(batch * 2 * sizeof(mpl_t));
-    if (!hX || !x3 || !dens || !pref) { free(hX); free(x3); free(dens); free(pref); return GECM_ERR_NOMEM; }
-    uint32_t *hZ = hX + words, *hS = hZ + words;
-    mpl_t *num = x3 + batch;
-    /* the two inversions per curve, mpz_invert(16u^3v) ecm.c:1745 and mpz_invert(v^3) ecm.c:1759,
-     * share the modulus across the whole batch: Montgomery's simultaneous inversion, one
-     * extended Euclid per batch instead of two per curve.  Inverses mod N are unique, so the
-     * values are the ones GMP returns. */
-    for (size_t i = 0; i < batch; i++)
-        suyama_pre(&c->N, sigma[i], &x3[i], &dens[2 * i + 1], &num[i], &dens[2 * i]);
-    size_t m = 2 * batch;
+    build_job *j = (build_job *)arg;
+    gecm_ctx *c = j->c;
+    const size_t cnt = j->hi - j->lo, m = 2 * cnt, batch = j->batch;
+    const int nl = c->nl;
+    j->rc = 0;
+    j->anybad = 0;
+    if (cnt == 0) return NULL;
+    mpl_t *x3 = (mpl_t *)malloc(cnt * sizeof(mpl_t) * 2);
+    mpl_t *dens = (mpl_t *)malloc(m * sizeof(mpl_t));
+    mpl_t *pref = (mpl_t *)malloc(m * sizeof(mpl_t));
+    if (!x3 || !dens || !pref) { free(x3); free(dens); free(pref); j->rc = GECM_ERR_NOMEM; return NULL; }
+    mpl_t *num = x3 + cnt;
+    for (size_t i = 0; i < cnt; i++)
+        suyama_pre(&c->N, j->sigma[j->lo + i], &x3[i], &dens[2 * i + 1], &num[i], &dens[2 * i]);
     int batch_ok = 1;
     pref[0] = dens[0];
     for (size_t i = 1; i < m; i++) mpl_mulmod(&pref[i], &pref[i - 1], &dens[i], &c->N);
@@ -386,25 +395,73 @@ int gecm_build_curves(gecm_ctx *c, const uint64_t *sigma, size_t batch)
          * flagged (a non-invertible denominator means gcd(denominator, N) is a factor). */
         for (size_t i = 0; i < m; i++)
             if (!mpl_invmod(&invs[i], &dens[i], &c->N)) {
-                c->bad[i / 2] = 1;
-                anybad = 1;
+                c->bad[j->lo + i / 2] = 1;
+                j->anybad = 1;
                 if ((i & 1) == 0) { mpl_mul_u64(&t, &x3[i / 2], 16); mpl_mod(&invs[i], &t, &c->N); }
                 else invs[i] = num[i / 2];
             }
     }
-    for (size_t i = 0; i < batch; i++) {
+    for (size_t i = 0; i < cnt; i++) {
         mpl_t A, X, Xm, Sm;
+        const size_t k = j->lo + i;
         mpl_mulmod(&A, &num[i], &invs[2 * i], &c->N);          /* b = a / 16u^3v   ecm.c:1752-1753 */
         mpl_mulmod(&X, &x3[i], &invs[2 * i + 1], &c->N);       /* X = u^3 / v^3, Z = 1  ecm.c:1759-1761 */
         /* into Montgomery form (ecm.c:1763-1772), internal radix */
         mpl_mulmod(&Xm, &X, &c->rint_mod_n, &c->N);
         mpl_mulmod(&Sm, &A, &c->rint_mod_n, &c->N);
-        mpl_to_limbs32(hX + i, batch, nl, LIMB_BITS, &Xm);
-        mpl_to_limbs32(hZ + i, batch, nl, LIMB_BITS, &c->rint_mod_n);
-        mpl_to_limbs32(hS + i, batch, nl, LIMB_BITS, &Sm);
+        mpl_to_limbs32(j->hX + k, batch, nl, LIMB_BITS, &Xm);
+        mpl_to_limbs32(j->hZ + k, batch, nl, LIMB_BITS, &c->rint_mod_n);
+        mpl_to_limbs32(j->hS + k, batch, nl, LIMB_BITS, &Sm);
     }
-    rc = gecm_dev_upload(c->dev, hX, hZ, hS);
-    free(hX); free(x3); free(dens); free(pref);
+    free(x3); free(dens); free(pref);
+    return NULL;
+}
+
+static int host_threads(void)
+{
+    /* worker threads for host-side batch work: GECM_HOST_THREADS, else min(8, online CPUs) */
+    const char *e = getenv("GECM_HOST_THREADS");
+    long n = e ? atol(e) : sysconf(_SC_NPROCESSORS_ONLN);
+    if (n < 1) n = 1;
+    if (!e && n > 8) n = 8;
+    if (n > 64) n = 64;
+    return (int)n;
+}
+
+int gecm_build_curves(gecm_ctx *c, const uint64_t *sigma, size_t batch)
+{
+    if (!c || !sigma || batch == 0) { set_err("gecm_build_curves: bad argument"); return GECM_ERR_ARG; }
+    int rc = alloc_batch(c, batch);
+    if (rc) return rc;
+    for (size_t i = 0; i < batch; i++) {
+        if (sigma[i] < 6) { set_err("gecm_build_curves: sigma[%zu] < 6", i); return GECM_ERR_ARG; }
+        c->sigma[i] = sigma[i];
+    }
+    size_t words = (size_t)c->nl * batch;
+    uint32_t *hX = (uint32_t *)calloc(words * 3, 4);
+    if (!hX) return GECM_ERR_NOMEM;
+    int nt = host_threads();
+    if ((size_t)nt > batch / 256 + 1) nt = (int)(batch / 256 + 1);
+    build_job jobs[64];
+    pthread_t th[64];
+    for (int t = 0; t < nt; t++) {
+        jobs[t].c = c; jobs[t].sigma = sigma; jobs[t].batch = batch;
+        jobs[t].lo = batch * (size_t)t / (size_t)nt;
+        jobs[t].hi = batch * (size_t)(t + 1) / (size_t)nt;
+        jobs[t].hX = hX; jobs[t].hZ = hX + words; jobs[t].hS = hX + 2 * words;
+    }
+    for (int t = 1; t < nt; t++)
+        if (pthread_create(&th[t], NULL, build_slice, &jobs[t])) { build_slice(&jobs[t]); th[t] = 0; }
+    build_slice(&jobs[0]);
+    int anybad = 0;
+    for (int t = 0; t < nt; t++) {
+        if (t > 0 && th[t]) pthread_join(th[t], NULL);
+        if (jobs[t].rc) rc = jobs[t].rc;
+        anybad |= jobs[t].anybad;
+    }
+    if (rc) { free(hX); return rc; }
+    rc = gecm_dev_upload(c->dev, hX, hX + words, hX + 2 * words);
+    free(hX);
     if (rc) { set_err("%s", gecm_dev_error()); return GECM_ERR_DEVICE; }
     return anybad ? 1 : GECM_OK;
 }
@@ -453,6 +510,7 @@ int gecm_stage1(gecm_ctx *c, uint64_t B1)
     c->have_plain = 0;
     c->have_acc = 0;
     c->s2_ready = 0;
+    c->scan_valid[0] = c->scan_valid[1] = 0;
     if (gecm_dev_stage1(c->dev)) { set_err("%s", gecm_dev_error()); return GECM_ERR_DEVICE; }
     return GECM_OK;
 }
@@ -545,10 +603,15 @@ int gecm_stage1_factor(gecm_ctx *c, size_t k, char *dec, size_t declen, int *is_
     int rc = fetch_plain(c);
     if (rc) return rc;
     mpl_t z, g;
-    mpl_from_limbs32(&z, c->hz + k, c->batch, c->nl, LIMB_BITS);
     /* check_factor, ecm.c:2542-2557: gcd(Z, N); the reference passes Z in Montgomery form, and
-     * gcd(z R mod N, N) = gcd(z, N) because R is a power of two and N is odd. */
-    mpl_gcd(&g, &z, &c->N);
+     * gcd(z R mod N, N) = gcd(z, N) because R is a power of two and N is odd.  If the device scan
+     * of this batch has run, its gcd is used; otherwise it is computed here. */
+    if (c->scan_valid[0] && c->hg[0]) {
+        mpl_from_limbs32(&g, c->hg[0] + k, c->batch, c->nl, LIMB_BITS);
+    } else {
+        mpl_from_limbs32(&z, c->hz + k, c->batch, c->nl, LIMB_BITS);
+        mpl_gcd(&g, &z, &c->N);
+    }
     if (mpl_cmp_u64(&g, 1) > 0 && mpl_cmp(&g, &c->N) != 0) {
         static __thread char tmp[MPL_MAXL * 10 + 16];
         int n = mpl_get_dec(tmp, &g);
@@ -664,6 +727,7 @@ int gecm_stage2_pair(gecm_ctx *c, uint32_t steps, const uint32_t *pm_v, const ui
     c->s2_ptadds += adds; c->s2_numinv += inv; c->s2_paired += paired; c->s2_devinv += devinv;
     c->s2_amin_last = run_amin;
     c->have_acc = 0;
+    c->scan_valid[1] = 0;
     return GECM_OK;
 }
 
@@ -725,8 +789,12 @@ int gecm_stage2_factor(gecm_ctx *c, size_t k, char *dec, size_t declen, int *is_
     mpl_t a, g;
     mpl_from_limbs32(&g, c->hfail + k, c->batch, c->nl, LIMB_BITS);
     if (mpl_is_zero(&g)) {
-        mpl_from_limbs32(&a, c->hacc + k, c->batch, c->nl, LIMB_BITS);
-        mpl_gcd(&g, &a, &c->N);                      /* check_factor, ecm.c:2542-2557 */
+        if (c->scan_valid[1] && c->hg[1]) {
+            mpl_from_limbs32(&g, c->hg[1] + k, c->batch, c->nl, LIMB_BITS);
+        } else {
+            mpl_from_limbs32(&a, c->hacc + k, c->batch, c->nl, LIMB_BITS);
+            mpl_gcd(&g, &a, &c->N);                  /* check_factor, ecm.c:2542-2557 */
+        }
     }
     if (mpl_cmp_u64(&g, 1) > 0 && mpl_cmp(&g, &c->N) != 0) {
         static __thread char tmp[MPL_MAXL * 10 + 16];
@@ -746,10 +814,11 @@ int gecm_scan_factors(gecm_ctx *c, int stage, size_t *first)
 {
     if (!c || c->batch == 0 || (stage != 1 && stage != 2)) { set_err("gecm_scan_factors: bad argument"); return GECM_ERR_ARG; }
     if (stage == 2 && !c->s2_ready) { set_err("gecm_scan_factors: no stage-2 state"); return GECM_ERR_STATE; }
-    uint32_t **f = &c->flags[stage - 1];
+    uint32_t **f = &c->flags[stage - 1], **hg = &c->hg[stage - 1];
     if (!*f) *f = (uint32_t *)calloc(c->batch, sizeof(uint32_t));
-    if (!*f) return GECM_ERR_NOMEM;
-    if (gecm_dev_gcd_scan(c->dev, stage - 1, *f, NULL)) { set_err("gecm_scan_factors: %s", gecm_dev_error()); return GECM_ERR_DEVICE; }
+    if (!*hg) *hg = (uint32_t *)calloc(c->batch * (size_t)c->nl, sizeof(uint32_t));
+    if (!*f || !*hg) return GECM_ERR_NOMEM;
+    if (gecm_dev_gcd_scan(c->dev, stage - 1, *f, *hg)) { set_err("gecm_scan_factors: %s", gecm_dev_error()); return GECM_ERR_DEVICE; }
     size_t n = 0, lo = c->batch;
     if (stage == 2) {
         /* a failed batch inversion also marks its curve (ecm.c:1927-1939) */
@@ -763,6 +832,7 @@ int gecm_scan_factors(gecm_ctx *c, int stage, size_t *first)
     }
     for (size_t k = 0; k < c->batch; k++)
         if ((*f)[k]) { n++; if (k < lo) lo = k; }
+    c->scan_valid[stage - 1] = 1;
     if (first) *first = lo;
     return (int)(n > 0x7fffffff ? 0x7fffffff : n);
 }
