@@ -351,7 +351,7 @@ extern "C" int gecm_dev_s2_init(gecm_dev *d, const uint32_t *keep, size_t keep_w
     a.bx = d->dBlk; a.bz = d->dBlk + (coord / 4) * GECM_S2_BLK; a.bp = d->dBlk + (coord / 4) * 2 * GECM_S2_BLK;
     a.PdX = d->dPd; a.PdZ = d->dPd + coord / 4;
     a.acc = d->dAcc; a.fail = d->dFail; a.keep = d->dKeep;
-    a.umax = umax; a.D = D; a.stride = d->stride;
+    a.umax = umax; a.D = D; a.npb = npb; a.stride = d->stride;
     gecm_modconst mc = modconst(d);
     HIPCHK(hipEventRecord(d->ev0, d->stream));
     switch (d->nl) {
@@ -386,7 +386,7 @@ extern "C" int gecm_dev_s2_pair(gecm_dev *d, const uint32_t *steps, uint32_t nst
     }
     if (nsteps) HIPCHK(hipMemcpyAsync(d->dSteps, steps, (size_t)nsteps * 8, hipMemcpyHostToDevice, d->stream));
     gecm_s2_pair_args a;
-    a.X = d->dX; a.Z = d->dZ; a.S = d->dS; a.PbX = d->dPbX;
+    a.X = d->dX; a.Z = d->dZ; a.S = d->dS; a.PbX = d->dPbX; a.npb = (uint32_t)d->s2_npb;
     a.PdX = d->dPd; a.PdZ = d->dPd + coord / 4;
     const size_t cw = coord / 4;
     a.gx = d->dPa; a.gz = a.gx + cw * ((size_t)G + 2); a.gp = a.gz + cw * ((size_t)G + 2); a.ring = a.gp + cw * (size_t)G;

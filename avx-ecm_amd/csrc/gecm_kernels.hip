@@ -196,7 +196,7 @@ extern "C" void CAT(gecm_launch_s2_init_, GECM_NL)(void *stream, const gecm_modc
     S2InitArgs a;
     a.X = h->X; a.Z = h->Z; a.S = h->S; a.PbX = h->PbX; a.bx = h->bx; a.bz = h->bz; a.bp = h->bp;
     a.PdX = h->PdX; a.PdZ = h->PdZ; a.acc = h->acc; a.fail = h->fail; a.keep = h->keep;
-    a.umax = h->umax; a.D = h->D; a.stride = h->stride;
+    a.umax = h->umax; a.D = h->D; a.npb = h->npb; a.stride = h->stride;
     hipLaunchKernelGGL(k_s2_init<GECM_NL>, dim3((unsigned)(h->stride / 64)), dim3(64), 0, (hipStream_t)stream, a,
                        make_s2<GECM_NL>(mc));
 }
@@ -204,7 +204,7 @@ extern "C" void CAT(gecm_launch_s2_init_, GECM_NL)(void *stream, const gecm_modc
 extern "C" void CAT(gecm_launch_s2_pair_, GECM_NL)(void *stream, const gecm_modconst *mc, const gecm_s2_pair_args *h)
 {
     S2PairArgs a;
-    a.X = h->X; a.Z = h->Z; a.S = h->S; a.PbX = h->PbX; a.PdX = h->PdX; a.PdZ = h->PdZ;
+    a.X = h->X; a.Z = h->Z; a.S = h->S; a.PbX = h->PbX; a.npb = h->npb; a.PdX = h->PdX; a.PdZ = h->PdZ;
     a.gx = h->gx; a.gz = h->gz; a.gp = h->gp; a.ring = h->ring; a.acc = h->acc; a.fail = h->fail;
     a.steps = h->steps; a.nsteps = h->nsteps; a.D = h->D; a.G = h->G; a.ring_size = h->ring_size; a.A0 = h->A0;
     a.stride = h->stride;

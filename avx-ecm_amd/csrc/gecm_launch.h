@@ -23,12 +23,13 @@ typedef struct {
     const uint32_t *X, *Z, *S;
     uint32_t *PbX, *bx, *bz, *bp, *PdX, *PdZ, *acc, *fail;
     const uint32_t *keep;
-    uint32_t umax, D;
+    uint32_t umax, D, npb;
     size_t stride;
 } gecm_s2_init_args;
 
 typedef struct {
     const uint32_t *X, *Z, *S, *PbX, *PdX, *PdZ;
+    uint32_t npb;
     uint32_t *gx, *gz, *gp, *ring, *acc, *fail;
     const uint32_t *steps;        /* device copy of the tape */
     const uint32_t *host_steps;   /* host copy: the launcher splits it at the "generate" marks */

@@ -34,16 +34,36 @@ struct S2Const {
     uint32_t inv_iters;   // 2 * bitlen(N)
 };
 
-// entry `e` of a table [entry][limb][curve]
+// Tables are tiled per wavefront: [wave][entry][limb][lane].  One entry of one wave is NL*256
+// contiguous bytes (3.84 KB at NL=15), so a pair step reads one contiguous chunk of the 60-GB
+// baby-step table instead of NL 256-byte pieces half a megabyte apart ([entry][limb][curve] order):
+// one DRAM page and one TLB entry per access instead of NL.
 template <int NL>
-__device__ __forceinline__ void tb_load(Fe<NL> &r, const uint32_t *__restrict__ base, size_t stride, uint32_t idx, size_t e)
+struct Tab {
+    uint32_t *base;
+    uint32_t nent;      // entries per wave
+};
+template <int NL>
+__device__ __forceinline__ const uint32_t *tb_ptr(const uint32_t *base, uint32_t nent, uint32_t idx, size_t e)
 {
-    fe_load(r, base + e * (size_t)NL * stride, stride, idx);
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(idx >> 6);
+    return base + ((size_t)wave * nent + e) * (size_t)(NL * 64);
 }
 template <int NL>
-__device__ __forceinline__ void tb_store(uint32_t *__restrict__ base, size_t stride, uint32_t idx, size_t e, const Fe<NL> &r)
+__device__ __forceinline__ void tb_load(Fe<NL> &r, const uint32_t *__restrict__ base, uint32_t nent, uint32_t idx, size_t e)
 {
-    fe_store(base + e * (size_t)NL * stride, stride, idx, r);
+    const char *p = (const char *)tb_ptr<NL>(base, nent, idx, e);
+    const uint32_t boff = (idx & 63u) * 4u;
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.v[i] = *(const uint32_t *)(p + i * 256 + boff);
+}
+template <int NL>
+__device__ __forceinline__ void tb_store(uint32_t *__restrict__ base, uint32_t nent, uint32_t idx, size_t e, const Fe<NL> &r)
+{
+    char *p = (char *)const_cast<uint32_t *>(tb_ptr<NL>(base, nent, idx, e));
+    const uint32_t boff = (idx & 63u) * 4u;
+#pragma unroll
+    for (int i = 0; i < NL; i++) *(uint32_t *)(p + i * 256 + boff) = r.v[i];
 }
 
 // ---- exact helpers on fully normalised values ----------------------------------------------
@@ -166,32 +186,33 @@ __device__ __forceinline__ void fe_inv_mont(Fe<NL> &r, const Fe<NL> &a, const S2
 // Montgomery's trick on n <= S2_BLK points whose X, Z sit in bx, bz (block tables):
 // out[e0 + i] = X_i / Z_i (Montgomery form, lazy-normalised).  bp = scratch for prefix products.
 template <int NL>
-__device__ __forceinline__ void block_normalise(uint32_t *__restrict__ out, size_t e0, const uint32_t *__restrict__ bx,
-                                                const uint32_t *__restrict__ bz, uint32_t *__restrict__ bp, uint32_t n,
-                                                const S2Const<NL> &k, uint32_t *__restrict__ fail, size_t stride, uint32_t idx)
+__device__ __forceinline__ void block_normalise(uint32_t *__restrict__ out, uint32_t out_nent, size_t e0,
+                                                const uint32_t *__restrict__ bx, const uint32_t *__restrict__ bz,
+                                                uint32_t *__restrict__ bp, uint32_t n, const S2Const<NL> &k,
+                                                uint32_t *__restrict__ fail, size_t stride, uint32_t idx)
 {
     Fe<NL> acc, z, x, t;
-    tb_load(acc, bz, stride, idx, 0);
-    tb_store(bp, stride, idx, 0, acc);
+    tb_load(acc, bz, S2_BLK, idx, 0);
+    tb_store(bp, S2_BLK, idx, 0, acc);
     for (uint32_t i = 1; i < n; i++) {            // prefix products  (ecm.c:1889-1893)
-        tb_load(z, bz, stride, idx, i);
+        tb_load(z, bz, S2_BLK, idx, i);
         fe_mul(acc, acc, z, k.m);
-        tb_store(bp, stride, idx, i, acc);
+        tb_store(bp, S2_BLK, idx, i, acc);
     }
     Fe<NL> inv;
     fe_inv_mont(inv, acc, k, fail, stride, idx);  // (prod Z)^-1
     for (uint32_t i = n - 1; i > 0; i--) {        // suffix walk  (ecm.c:1965-1987)
-        tb_load(t, bp, stride, idx, i - 1);
+        tb_load(t, bp, S2_BLK, idx, i - 1);
         fe_mul(t, t, inv, k.m);                   // Z_i^-1
-        tb_load(z, bz, stride, idx, i);
+        tb_load(z, bz, S2_BLK, idx, i);
         fe_mul(inv, inv, z, k.m);
-        tb_load(x, bx, stride, idx, i);
+        tb_load(x, bx, S2_BLK, idx, i);
         fe_mul(x, x, t, k.m);
-        tb_store(out, stride, idx, e0 + i, x);
+        tb_store(out, out_nent, idx, e0 + i, x);
     }
-    tb_load(x, bx, stride, idx, 0);
+    tb_load(x, bx, S2_BLK, idx, 0);
     fe_mul(x, x, inv, k.m);
-    tb_store(out, stride, idx, e0, x);
+    tb_store(out, out_nent, idx, e0, x);
 }
 
 // P <- [c]P, binary ladder (next_pt_vec, ecm.c:886-976); c is wave-uniform.
@@ -234,7 +255,7 @@ struct S2InitArgs {
     uint32_t *acc;                   // out: accumulator = one
     uint32_t *fail;                  // per-curve gcd record of a failed inversion (zeroed by host)
     const uint32_t *keep;            // bitmap over j: bit j set iff map[j] > 0
-    uint32_t umax, D;
+    uint32_t umax, D, npb;
     size_t stride;
 };
 
@@ -253,8 +274,8 @@ __device__ __forceinline__ void s2_init(const S2InitArgs &a, const S2Const<NL> &
     pt_dup(P1, sQ, dQ, s4, m);                 // [2]Q     ecm.c:2243-2244
     P3 = Q;
     // entries 1 and 2
-    tb_store(a.bx, stride, idx, 0, Q.X);  tb_store(a.bz, stride, idx, 0, Q.Z);
-    tb_store(a.bx, stride, idx, 1, P1.X); tb_store(a.bz, stride, idx, 1, P1.Z);
+    tb_store(a.bx, S2_BLK, idx, 0, Q.X);  tb_store(a.bz, S2_BLK, idx, 0, Q.Z);
+    tb_store(a.bx, S2_BLK, idx, 1, P1.X); tb_store(a.bz, S2_BLK, idx, 1, P1.Z);
     uint32_t nblk = 2, e0 = 1;
     for (uint32_t j = 3; j <= a.umax; j++) {    // ecm.c:2263-2313
         Fe<NL> s1, d1, pp, mm;
@@ -266,11 +287,11 @@ __device__ __forceinline__ void s2_init(const S2InitArgs &a, const S2Const<NL> &
         uint32_t kb = (a.keep[j >> 5] >> (j & 31)) & 1u;
         kb = __builtin_amdgcn_readfirstlane(kb);
         if (kb) {
-            tb_store(a.bx, stride, idx, nblk, T.X);
-            tb_store(a.bz, stride, idx, nblk, T.Z);
+            tb_store(a.bx, S2_BLK, idx, nblk, T.X);
+            tb_store(a.bz, S2_BLK, idx, nblk, T.Z);
             nblk++;
             if (nblk == S2_BLK) {
-                block_normalise<NL>(a.PbX, e0, a.bx, a.bz, a.bp, nblk, k, a.fail, stride, idx);
+                block_normalise<NL>(a.PbX, a.npb, e0, a.bx, a.bz, a.bp, nblk, k, a.fail, stride, idx);
                 e0 += nblk;
                 nblk = 0;
             }
@@ -278,7 +299,7 @@ __device__ __forceinline__ void s2_init(const S2InitArgs &a, const S2Const<NL> &
         P3 = P1;
         P1 = T;
     }
-    if (nblk) block_normalise<NL>(a.PbX, e0, a.bx, a.bz, a.bp, nblk, k, a.fail, stride, idx);
+    if (nblk) block_normalise<NL>(a.PbX, a.npb, e0, a.bx, a.bz, a.bp, nblk, k, a.fail, stride, idx);
     Pt<NL> Pd = Q;
     pt_ladder(Pd, (uint64_t)a.D, s4, m);        // Pd = [w]Q   ecm.c:2332-2334
     Fe<NL> c;
@@ -290,6 +311,7 @@ __device__ __forceinline__ void s2_init(const S2InitArgs &a, const S2Const<NL> &
 struct S2PairArgs {
     const uint32_t *X, *Z, *S;       // Q, s
     const uint32_t *PbX;             // normalised baby steps
+    uint32_t npb;
     const uint32_t *PdX, *PdZ;       // Pd = [D]Q
     uint32_t *gx, *gz;               // chunk scratch: X, Z of the giant steps being generated, G+2 entries
                                      // (entries 0,1 = the last two steps of the previous chunk)
@@ -343,14 +365,14 @@ __device__ __forceinline__ void giant_chunk(const S2PairArgs &a, uint32_t first_
         pt_add_uv(pp, mm, s1, d1, sD, dD, m);
         fe_mul(T.X, pp, Pad.Z, m);                    // Pa[1] = Pa[0] + Pd (Pad)   ecm.c:2395-2401
         fe_mul(T.Z, mm, Pad.X, m);
-        tb_store(a.gx, stride, idx, 2, P0.X); tb_store(a.gz, stride, idx, 2, P0.Z);
-        tb_store(a.gx, stride, idx, 3, T.X);  tb_store(a.gz, stride, idx, 3, T.Z);
+        tb_store(a.gx, a.G + 2, idx, 2, P0.X); tb_store(a.gz, a.G + 2, idx, 2, P0.Z);
+        tb_store(a.gx, a.G + 2, idx, 3, T.X);  tb_store(a.gz, a.G + 2, idx, 3, T.Z);
         p2 = P0;
         p1 = T;
         start = 2;
     } else {
-        tb_load(p2.X, a.gx, stride, idx, 0); tb_load(p2.Z, a.gz, stride, idx, 0);
-        tb_load(p1.X, a.gx, stride, idx, 1); tb_load(p1.Z, a.gz, stride, idx, 1);
+        tb_load(p2.X, a.gx, a.G + 2, idx, 0); tb_load(p2.Z, a.gz, a.G + 2, idx, 0);
+        tb_load(p1.X, a.gx, a.G + 2, idx, 1); tb_load(p1.Z, a.gz, a.G + 2, idx, 1);
     }
     for (uint32_t i = start; i < n; i++) {            // Pa[i] = Pa[i-1] + Pd, difference Pa[i-2]  ecm.c:2412-2416
         Pt<NL> T;
@@ -359,38 +381,38 @@ __device__ __forceinline__ void giant_chunk(const S2PairArgs &a, uint32_t first_
         pt_add_uv(pp, mm, s1, d1, sD, dD, m);
         fe_mul(T.X, pp, p2.Z, m);
         fe_mul(T.Z, mm, p2.X, m);
-        tb_store(a.gx, stride, idx, i + 2, T.X);
-        tb_store(a.gz, stride, idx, i + 2, T.Z);
+        tb_store(a.gx, a.G + 2, idx, i + 2, T.X);
+        tb_store(a.gz, a.G + 2, idx, i + 2, T.Z);
         p2 = p1;
         p1 = T;
     }
     // the last two steps seed the next chunk
-    tb_store(a.gx, stride, idx, 0, p2.X); tb_store(a.gz, stride, idx, 0, p2.Z);
-    tb_store(a.gx, stride, idx, 1, p1.X); tb_store(a.gz, stride, idx, 1, p1.Z);
+    tb_store(a.gx, a.G + 2, idx, 0, p2.X); tb_store(a.gz, a.G + 2, idx, 0, p2.Z);
+    tb_store(a.gx, a.G + 2, idx, 1, p1.X); tb_store(a.gz, a.G + 2, idx, 1, p1.Z);
     // Montgomery's trick over the chunk (ecm.c:2003-2136), results into the ring
     Fe<NL> acc, z, x, t;
-    tb_load(acc, a.gz, stride, idx, 2);
-    tb_store(a.gp, stride, idx, 0, acc);
+    tb_load(acc, a.gz, a.G + 2, idx, 2);
+    tb_store(a.gp, a.G, idx, 0, acc);
     for (uint32_t i = 1; i < n; i++) {
-        tb_load(z, a.gz, stride, idx, i + 2);
+        tb_load(z, a.gz, a.G + 2, idx, i + 2);
         fe_mul(acc, acc, z, m);
-        tb_store(a.gp, stride, idx, i, acc);
+        tb_store(a.gp, a.G, idx, i, acc);
     }
     Fe<NL> inv;
     fe_inv_mont(inv, acc, k, a.fail, stride, idx);
     const uint32_t rmask = a.ring_size - 1;
     for (uint32_t i = n - 1; i > 0; i--) {
-        tb_load(t, a.gp, stride, idx, i - 1);
+        tb_load(t, a.gp, a.G, idx, i - 1);
         fe_mul(t, t, inv, m);
-        tb_load(z, a.gz, stride, idx, i + 2);
+        tb_load(z, a.gz, a.G + 2, idx, i + 2);
         fe_mul(inv, inv, z, m);
-        tb_load(x, a.gx, stride, idx, i + 2);
+        tb_load(x, a.gx, a.G + 2, idx, i + 2);
         fe_mul(x, x, t, m);
-        tb_store(a.ring, stride, idx, (first_abs + i) & rmask, x);
+        tb_store(a.ring, a.ring_size, idx, (first_abs + i) & rmask, x);
     }
-    tb_load(x, a.gx, stride, idx, 2);
+    tb_load(x, a.gx, a.G + 2, idx, 2);
     fe_mul(x, x, inv, m);
-    tb_store(a.ring, stride, idx, first_abs & rmask, x);
+    tb_store(a.ring, a.ring_size, idx, first_abs & rmask, x);
 }
 
 // The pair walk of ecm_stage2_pair (ecm.c:2448-2533) over tape entries [first, first+count): every
@@ -404,28 +426,56 @@ __device__ __forceinline__ void s2_pairs(const S2PairArgs &a, uint32_t first, ui
     if (count == 0) return;
     Fe<NL> acc;
     fe_load(acc, a.acc, stride, idx);
-    // One-step lookahead: the two table rows of the NEXT pair are requested before the multiply of the
-    // current one, so their HBM latency (the ring and the 461-KB-per-curve baby-step table do not stay
-    // in cache) hides behind ~2k cycles of arithmetic.
+    // Lookahead: the baby-step rows of the next DEPTH pairs are in flight while the current pair is
+    // multiplied, so HBM latency (2-3 us under load) hides behind the arithmetic.  The host sorts the
+    // pairs of a segment by giant step (the product is order-independent), so the ring row is
+    // re-read only when the giant step changes: per pair one 4*NL-byte row of the 461-KB-per-curve
+    // baby-step table comes from HBM instead of two rows (the walk is HBM-bound otherwise:
+    // 2*60 B x 131,072 curves x 3.0 M pairs = 47 TB at B2 = 1e8).
     const uint32_t *st = a.steps + 2 * (size_t)first;
-    Fe<NL> x, y, xn, yn;
-    uint32_t w0 = __builtin_amdgcn_readfirstlane(st[0]), w1 = __builtin_amdgcn_readfirstlane(st[1]);
-    tb_load(x, a.ring, stride, idx, w0);
-    tb_load(y, a.PbX, stride, idx, w1);
-    for (uint32_t i = 0; i < count; i++) {
-        const bool more = i + 1 < count;
-        if (more) {
-            w0 = __builtin_amdgcn_readfirstlane(st[2 * i + 2]);
-            w1 = __builtin_amdgcn_readfirstlane(st[2 * i + 3]);
-            tb_load(xn, a.ring, stride, idx, w0);
-            tb_load(yn, a.PbX, stride, idx, w1);
+    constexpr int DEPTH = 4;                          // table rows in flight per lane
+    Fe<NL> x, yq[DEPTH];
+    // tape words are fetched one group ahead too (scalar loads): cs = giant-step slots of the current
+    // group of DEPTH pairs, rb = table indices of the group after it (the rows to request next)
+    auto word = [&](uint32_t j, uint32_t w) -> uint32_t {
+        const uint32_t jj = j < count ? j : count - 1;       // clamp: never read past the segment
+        return __builtin_amdgcn_readfirstlane(st[2 * jj + w]);
+    };
+    uint32_t cs[DEPTH], rb[DEPTH], ns[DEPTH], nr[DEPTH];
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++) {
+        cs[d] = word((uint32_t)d, 0);
+        rb[d] = word((uint32_t)(d + DEPTH), 1);
+    }
+    uint32_t slot = cs[0];
+    tb_load(x, a.ring, a.ring_size, idx, slot);
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++)
+        if ((uint32_t)d < count) tb_load(yq[d], a.PbX, a.npb, idx, word((uint32_t)d, 1));
+    for (uint32_t i = 0; i < count; i += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; d++) {
+            ns[d] = word(i + DEPTH + (uint32_t)d, 0);
+            nr[d] = word(i + 2 * DEPTH + (uint32_t)d, 1);
         }
-        Fe<NL> t;
-        fe_sub(t, x, y, m);                           // CROSS_PRODUCT_INV  ecm.c:1857-1859
-        fe_mul(acc, acc, t, m);
-        if (more) {
-            x = xn;
-            y = yn;
+#pragma unroll
+        for (int d = 0; d < DEPTH; d++) {
+            const uint32_t j = i + (uint32_t)d;
+            if (j < count) {
+                if (cs[d] != slot) {                  // next giant step (pairs are sorted by it)
+                    slot = cs[d];
+                    tb_load(x, a.ring, a.ring_size, idx, slot);
+                }
+                Fe<NL> t;
+                fe_sub(t, x, yq[d], m);               // CROSS_PRODUCT_INV  ecm.c:1857-1859
+                fe_mul(acc, acc, t, m);
+                if (j + DEPTH < count) tb_load(yq[d], a.PbX, a.npb, idx, rb[d]);
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < DEPTH; d++) {
+            cs[d] = ns[d];
+            rb[d] = nr[d];
         }
     }
     Fe<NL> c;

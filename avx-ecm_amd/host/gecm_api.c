@@ -678,6 +678,13 @@ void gecm_pairmap_release(gecm_pairs *p)
     memset(p, 0, sizeof *p);
 }
 
+static int cmp_pair_slot(const void *a, const void *b)
+{
+    const uint32_t *x = (const uint32_t *)a, *y = (const uint32_t *)b;
+    if (x[0] != y[0]) return x[0] < y[0] ? -1 : 1;
+    return x[1] < y[1] ? -1 : (x[1] > y[1]);
+}
+
 int gecm_stage2_pair(gecm_ctx *c, uint32_t steps, const uint32_t *pm_v, const uint32_t *pm_u, uint32_t amin)
 {
     if (!c || !c->s2_ready) { set_err("gecm_stage2_pair: gecm_stage2_init has not run"); return GECM_ERR_STATE; }
@@ -719,6 +726,16 @@ int gecm_stage2_pair(gecm_ctx *c, uint32_t steps, const uint32_t *pm_v, const ui
         }
     }
 #undef NEED
+    /* Within a segment (between two "generate" marks) the accumulator is a plain product, so the
+     * pairs may be taken in any order: sort them by giant step so the device re-reads a ring row only
+     * when it changes (csrc/gecm_stage2.hpp, s2_pairs). */
+    for (size_t i = 0; i < nt;) {
+        if (tape[i] == 0xffffffffu) { i += 2; continue; }
+        size_t j = i;
+        while (j < nt && tape[j] != 0xffffffffu) j += 2;
+        qsort(tape + i, (j - i) / 2, 2 * sizeof(uint32_t), cmp_pair_slot);
+        i = j;
+    }
     uint64_t A0 = (uint64_t)amin * p->D * 2;                             /* ecm.c:2378 */
     adds += ladder_adds(A0) + ladder_adds(A0 - p->D);                    /* ecm.c:2383, 2390 */
     int rc = gecm_dev_s2_pair(c->dev, tape, (uint32_t)(nt / 2), p->D, S2_GIANT_CHUNK, S2_RING, A0);
