@@ -23,26 +23,6 @@ struct Pt {
     Fe<NL> X, Z;
 };
 
-// Pout = P1 + P2 given sums/differences of P1 and P2 and the difference point Pd.
-// ecm.c:417-440: U = d1*s2, V = s1*d2, X+ = Zd*(U+V)^2, Z+ = Xd*(U-V)^2
-template <int NL>
-__device__ __forceinline__ void pt_add(Pt<NL> &out, const Fe<NL> &s1, const Fe<NL> &d1, const Fe<NL> &s2,
-                                       const Fe<NL> &d2, const Pt<NL> &pd, const ModK<NL> &m)
-{
-    Fe<NL> u, v, p, q;
-    fe_mul(u, d1, s2, m);   // U
-    fe_mul(v, s1, d2, m);   // V
-    fe_add(p, u, v);        // U + V
-    fe_sub(q, u, v, m);     // U - V
-    fe_sqr(p, p, m);        // (U+V)^2
-    fe_sqr(q, q, m);        // (U-V)^2
-    Fe<NL> x, z;
-    fe_mul(x, p, pd.Z, m);  // Z- * (U+V)^2
-    fe_mul(z, q, pd.X, m);  // X- * (U-V)^2
-    out.X = x;
-    out.Z = z;
-}
-
 // P = 2*(point whose sum/diff are s, d).  ecm.c:447-454.
 template <int NL>
 __device__ __forceinline__ void pt_dup(Pt<NL> &out, const Fe<NL> &s, const Fe<NL> &d, const Fe<NL> &s4,

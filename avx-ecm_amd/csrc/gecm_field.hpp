@@ -294,20 +294,6 @@ __device__ __forceinline__ void fe_sub(Fe<NL> &r, const Fe<NL> &a, const Fe<NL> 
     if (LazyPolicy<NL>::norm_sub) fe_weak_norm(r);
 }
 
-// Full carry propagation: limbs < 2^28 (top limb takes the rest).
-template <int NL>
-__device__ __forceinline__ void fe_full_norm(Fe<NL> &r)
-{
-    uint32_t c = 0;
-#pragma unroll
-    for (int i = 0; i < NL - 1; i++) {
-        uint32_t t = r.v[i] + c;
-        r.v[i] = t & GECM_LIMB_MASK;
-        c = t >> GECM_LIMB_BITS;
-    }
-    r.v[NL - 1] += c;
-}
-
 // Canonical residue in [0, N) of a fully normalised value < 2N.
 template <int NL>
 __device__ __forceinline__ void fe_cond_sub_n(Fe<NL> &r, const ModK<NL> &m)
