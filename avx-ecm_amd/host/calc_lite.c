@@ -5,7 +5,9 @@
  * covering the operators a factoring command line uses:
  *     + - * / % ^      binary, usual precedence, ^ right-associative, / exact or truncating
  *     n!  n#           factorial and primorial (postfix)
+ *     << >>            shifts (lowest precedence, as in the reference's table calc.c:1106-1126)
  *     fib(n) luc(n)    Fibonacci and Lucas numbers
+ *     gcd(a,b) sqrt(a) modinv(a,m) modexp(a,e,m)
  *     ( )              grouping; decimal or 0x-hex literals
  * Values are non-negative and bounded by the mpl capacity (4352 bits); a subtraction that would go
  * negative or an overflow is an error (return code != 0), never a wrong number.
@@ -56,15 +58,46 @@ static void primary(P *p, mpl_t *r)
         skip(p);
         if (*p->s != '(') { p->err = 1; return; }
         p->s++;
-        mpl_t arg;
-        expr(p, &arg);
-        skip(p);
-        if (p->err || *p->s != ')') { p->err = 1; return; }
+        mpl_t arg[3];
+        int na = 0;
+        for (;;) {
+            if (na == 3) { p->err = 1; return; }
+            expr(p, &arg[na++]);
+            skip(p);
+            if (p->err) return;
+            if (*p->s == ',') { p->s++; continue; }
+            break;
+        }
+        if (*p->s != ')') { p->err = 1; return; }
         p->s++;
-        if (arg.n > 1 || mpl_get_u64(&arg) > 100000) { p->err = 1; return; }
-        if (!strcmp(name, "fib")) fibluc(p, r, mpl_get_u64(&arg), 0);
-        else if (!strcmp(name, "luc")) fibluc(p, r, mpl_get_u64(&arg), 1);
-        else p->err = 1;
+        if ((!strcmp(name, "fib") || !strcmp(name, "luc")) && na == 1) {
+            if (arg[0].n > 1 || mpl_get_u64(&arg[0]) > 100000) { p->err = 1; return; }
+            fibluc(p, r, mpl_get_u64(&arg[0]), name[0] == 'l');
+        } else if (!strcmp(name, "gcd") && na == 2) {
+            mpl_gcd(r, &arg[0], &arg[1]);
+        } else if (!strcmp(name, "modinv") && na == 2) {
+            if (mpl_is_zero(&arg[1]) || !mpl_invmod(r, &arg[0], &arg[1])) p->err = 1;
+        } else if (!strcmp(name, "modexp") && na == 3) {
+            if (mpl_is_zero(&arg[2])) p->err = 1;
+            else mpl_powmod(r, &arg[0], &arg[1], &arg[2]);
+        } else if (!strcmp(name, "sqrt") && na == 1) {
+            /* integer square root by bisection on the bit length */
+            mpl_t lo, hi, mid, sq, one;
+            mpl_set_u64(&lo, 0);
+            mpl_set_u64(&one, 1);
+            mpl_shl(&hi, &one, (unsigned)(mpl_bits(&arg[0]) / 2 + 1));
+            while (mpl_cmp(&lo, &hi) < 0) {           /* invariant: lo^2 <= a < (hi+1)^2 */
+                mpl_add(&mid, &lo, &hi);
+                mpl_add(&mid, &mid, &one);
+                mpl_shr(&mid, &mid, 1);
+                mpl_mul(&sq, &mid, &mid);
+                if (mpl_cmp(&sq, &arg[0]) <= 0) lo = mid;
+                else mpl_sub(&hi, &mid, &one);
+            }
+            *r = lo;
+        } else {
+            p->err = 1;
+        }
     } else if (isdigit((unsigned char)*p->s)) {
         char buf[2048];
         int k = 0;
@@ -150,7 +183,7 @@ static void term(P *p, mpl_t *r)
     }
 }
 
-static void expr(P *p, mpl_t *r)
+static void sum(P *p, mpl_t *r)
 {
     term(p, r);
     for (;;) {
@@ -166,6 +199,28 @@ static void expr(P *p, mpl_t *r)
         else {
             if (mpl_cmp(r, &b) < 0) { p->err = 1; return; }
             mpl_sub(r, r, &b);
+        }
+    }
+}
+
+static void expr(P *p, mpl_t *r)
+{
+    sum(p, r);
+    for (;;) {
+        skip(p);
+        if (p->err) return;
+        if (!((p->s[0] == '<' && p->s[1] == '<') || (p->s[0] == '>' && p->s[1] == '>'))) return;
+        int left = p->s[0] == '<';
+        p->s += 2;
+        mpl_t b;
+        sum(p, &b);
+        if (p->err || b.n > 1 || mpl_get_u64(&b) > 4000) { p->err = 1; return; }
+        unsigned k = (unsigned)mpl_get_u64(&b);
+        if (left) {
+            if (mpl_bits(r) + (int)k > MPL_MAXL * 32 - 64) { p->err = 1; return; }
+            mpl_shl(r, r, k);
+        } else {
+            mpl_shr(r, r, k);
         }
     }
 }

@@ -185,3 +185,35 @@ def test_cli_without_gpu_fails_loudly():
     assert p.returncode == 2 and "no HIP device" in p.stderr
     p = subprocess.run([exe, "2^64", "8", "1000"], capture_output=True, text=True)       # even input
     assert p.returncode == 1 and "odd integer" in p.stdout
+
+
+def test_input_expression_evaluator(lib):
+    """calc_lite (host/calc_lite.c): the command line's first argument is an expression, as in the
+    reference (calc.c, README.md:30); config 1 of BASELINE.json uses one."""
+    import math
+    MAXL = 136
+
+    class M(ctypes.Structure):
+        _fields_ = [("n", ctypes.c_int), ("d", ctypes.c_uint32 * MAXL)]
+
+    def ev(s):
+        m = M()
+        return None if lib.calc_lite(ctypes.byref(m), s.encode()) else sum(m.d[i] << (32 * i) for i in range(m.n))
+
+    def fib(n):
+        a, b = 0, 1
+        for _ in range(n):
+            a, b = b, a + b
+        return a
+
+    n1 = fib(791) // 13 // 677 // 216416017
+    assert ev("fib(791)/13/677/216416017") == n1 and n1.bit_length() == 508      # SURVEY appendix B
+    assert ev("2^127-1") == 2 ** 127 - 1 and ev("2^3^2") == 512
+    assert ev("20!+1") == math.factorial(20) + 1 and ev("31#") == 200560490130
+    assert ev("luc(10)") == 123 and ev("0x10+1") == 17 and ev(" 7 * ( 3 + 4 ) ") == 49
+    assert ev("(2^64+13)*3 % 1000") == (2 ** 64 + 13) * 3 % 1000
+    assert ev("gcd(2^64-1, 2^32-1)") == 2 ** 32 - 1 and ev("sqrt(10^40+12345)") == math.isqrt(10 ** 40 + 12345)
+    assert ev("modinv(3, 1000003)") == pow(3, -1, 1000003) and ev("modexp(2, 1000, 10^9+7)") == pow(2, 1000, 10 ** 9 + 7)
+    assert ev("1<<100") == 1 << 100 and ev("(2^200+5)>>3") == (2 ** 200 + 5) >> 3
+    for bad in ("3-5", "1/0", "foo(3)", "2^100000", "(1+2", "", "modinv(2,4)"):
+        assert ev(bad) is None
