@@ -10,12 +10,19 @@
 #ifndef GECM_NL
 #error "compile with -DGECM_NL=<limbs>"
 #endif
+// GECM_PART splits one limb count over two objects so the build parallelises better:
+//   1 = stage 1, de-Montgomeryisation, L0 operators, factor scan;  2 = stage 2;  unset = both.
+#ifndef GECM_PART
+#define GECM_PART 0
+#endif
+#define GECM_HAS_PART(p) (GECM_PART == 0 || GECM_PART == (p))
 
 template <int NL>
 struct ModArgs {
     ModK<NL> m;
     Fe<NL> one;   // R mod N, canonical
 };
+#if GECM_HAS_PART(1)
 // ---------------------------------------------------------------- stage 1
 // One curve per lane.  64-thread blocks (one wave): a CU holds 8 of them at 2 waves/SIMD, the
 // occupancy at which v_mad_u64_u32 issues back-to-back (profiles/r01_valu_ubench_gfx950.txt).
@@ -88,27 +95,6 @@ k_l0(int op, const uint32_t *__restrict__ A, const uint32_t *__restrict__ B, uin
 }
 
 
-// ---------------------------------------------------------------- stage 2
-template <int NL>
-__global__ void __launch_bounds__(64, 2) k_s2_init(S2InitArgs a, S2Const<NL> k)
-{
-    s2_init<NL>(a, k, blockIdx.x * 64u + threadIdx.x);
-}
-
-// giant steps [first_abs, first_abs+n): generate + normalise into the ring
-template <int NL>
-__global__ void __launch_bounds__(64, 2) k_s2_gen(S2PairArgs a, uint32_t first_abs, uint32_t n, S2Const<NL> k)
-{
-    giant_chunk<NL>(a, first_abs, n, first_abs == 0, k, blockIdx.x * 64u + threadIdx.x);
-}
-
-// pair walk over tape entries [first, first+count)
-template <int NL>
-__global__ void __launch_bounds__(64, 2) k_s2_pairs(S2PairArgs a, uint32_t first, uint32_t count, S2Const<NL> k)
-{
-    s2_pairs<NL>(a, first, count, k, blockIdx.x * 64u + threadIdx.x);
-}
-
 // ---------------------------------------------------------------- factor scan
 // check_factor (ecm.c:2542-2557) for every curve on the device: g = gcd(v, N) by the same
 // fixed-iteration binary algorithm the stage-2 inversion uses; flag = 1 iff 1 < g < N.
@@ -133,6 +119,30 @@ k_gcd_scan(const uint32_t *__restrict__ V, uint32_t *__restrict__ G, uint32_t *_
     flags[idx] = (!is_one && !is_n) ? 1u : 0u;
 }
 
+#endif
+#if GECM_HAS_PART(2)
+// ---------------------------------------------------------------- stage 2
+template <int NL>
+__global__ void __launch_bounds__(64, 2) k_s2_init(S2InitArgs a, S2Const<NL> k)
+{
+    s2_init<NL>(a, k, blockIdx.x * 64u + threadIdx.x);
+}
+
+// giant steps [first_abs, first_abs+n): generate + normalise into the ring
+template <int NL>
+__global__ void __launch_bounds__(64, 2) k_s2_gen(S2PairArgs a, uint32_t first_abs, uint32_t n, S2Const<NL> k)
+{
+    giant_chunk<NL>(a, first_abs, n, first_abs == 0, k, blockIdx.x * 64u + threadIdx.x);
+}
+
+// pair walk over tape entries [first, first+count)
+template <int NL>
+__global__ void __launch_bounds__(64, 2) k_s2_pairs(S2PairArgs a, uint32_t first, uint32_t count, S2Const<NL> k)
+{
+    s2_pairs<NL>(a, first, count, k, blockIdx.x * 64u + threadIdx.x);
+}
+
+#endif
 // ---------------------------------------------------------------- launchers (C linkage)
 template <int NL>
 static ModArgs<NL> make_args(const gecm_modconst *mc)
@@ -165,6 +175,7 @@ static S2Const<NL> make_s2(const gecm_modconst *mc)
 #define CAT_(a, b) a##b
 #define CAT(a, b) CAT_(a, b)
 
+#if GECM_HAS_PART(1)
 extern "C" void CAT(gecm_launch_stage1_, GECM_NL)(void *stream, const gecm_modconst *mc, const uint32_t *tape,
                                                    uint32_t tape_len, uint32_t *X, uint32_t *Z,
                                                    const uint32_t *S, size_t stride)
@@ -190,7 +201,8 @@ extern "C" void CAT(gecm_launch_l0_, GECM_NL)(void *stream, const gecm_modconst 
     hipLaunchKernelGGL(k_l0<GECM_NL>, dim3((unsigned)(stride / 64)), dim3(64), 0, (hipStream_t)stream, op, A, B, C,
                        D, stride, make_args<GECM_NL>(mc), f);
 }
-
+#endif
+#if GECM_HAS_PART(2)
 extern "C" void CAT(gecm_launch_s2_init_, GECM_NL)(void *stream, const gecm_modconst *mc, const gecm_s2_init_args *h)
 {
     S2InitArgs a;
@@ -227,10 +239,12 @@ extern "C" void CAT(gecm_launch_s2_pair_, GECM_NL)(void *stream, const gecm_modc
         }
     }
 }
-
+#endif
+#if GECM_HAS_PART(1)
 extern "C" void CAT(gecm_launch_gcd_scan_, GECM_NL)(void *stream, const gecm_modconst *mc, const uint32_t *V,
                                                      uint32_t *G, uint32_t *flags, size_t stride)
 {
     hipLaunchKernelGGL(k_gcd_scan<GECM_NL>, dim3((unsigned)(stride / 64)), dim3(64), 0, (hipStream_t)stream, V, G, flags,
                        stride, make_s2<GECM_NL>(mc));
 }
+#endif
