@@ -11,7 +11,7 @@ extern "C" {
 #ifdef GECM_DEV_NL15
 #define GECM_NL_LIST(X) X(15)      /* `make DEV=1`: quick developer build, 416-bit class only */
 #else
-#define GECM_NL_LIST(X) X(8) X(12) X(15) X(19) X(23) X(26) X(30) X(34) X(37)
+#define GECM_NL_LIST(X) X(8) X(10) X(12) X(14) X(15) X(17) X(19) X(21) X(23) X(26) X(28) X(30) X(32) X(34) X(37)
 #endif
 
 typedef struct {

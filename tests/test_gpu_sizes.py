@@ -1,4 +1,4 @@
-"""GPU parity across every built limb count (NL in {8,12,15,19,23,26,30,34,37}) and ragged batch
+"""GPU parity across every built limb count (NL = 8 ... 37, 15 sizes) and ragged batch
 sizes.  Inputs without small factors are built from Mersenne primes so that no curve hits the
 degenerate "factor already found" path.  Checks: L0 operators against Python integers (the
 mathematical definition the reference's operators satisfy, verified in tests/golden/l0.json),
@@ -13,10 +13,16 @@ from conftest import ROOT
 
 pytestmark = pytest.mark.gpu
 
-M = {p: (1 << p) - 1 for p in (61, 89, 107, 127, 521, 607)}
+M = {p: (1 << p) - 1 for p in (13, 17, 19, 31, 61, 89, 107, 127, 521, 607)}
 # bits -> device limb count NL = smallest built size >= ceil((bits+5)/28)
 CASES = [
     ("M89*M107", M[89] * M[107], 8),                       # 196 bits
+    ("M127*M107", M[127] * M[107], 10),                    # 234 bits
+    ("M127*M107*M89*M61", M[127] * M[107] * M[89] * M[61], 14),            # 384 bits
+    ("M127*M107*M89*M61*M31*M19*M17*M13", M[127] * M[107] * M[89] * M[61] * M[31] * M[19] * M[17] * M[13], 17),  # 464
+    ("M521*M61", M[521] * M[61], 21),                      # 582 bits
+    ("M607*M127*M31*M13", M[607] * M[127] * M[31] * M[13], 28),            # 778 bits
+    ("M607*M127*M107*M31*M17", M[607] * M[127] * M[107] * M[31] * M[17], 32),  # 889 bits
     ("M127*M89*M107", M[127] * M[89] * M[107], 12),        # 323 bits
     ("M521", M[521], 19),                                  # 521 bits
     ("M521*M127", M[521] * M[127], 26),                    # 648 bits
