@@ -12,8 +12,9 @@
  *     ecm -resume save_b1.txt <B1> <B2>
  * Defaults as the reference: B2 = 100*B1 (main.c:462), B2 <= B1 disables stage 2
  * (main.c:548-552), sigma = 0 draws random 64-bit sigmas >= 6 (ecm.c:1564-1570).
- * Curves are processed in batches; the run stops after the batch in which a factor is found
- * (ecm.c:1531-1532).
+ * Curves are processed in batches (here up to 131072 per GPU, in the reference 8 per thread); the run
+ * stops after the batch in which a factor is found (ecm.c:1531-1532).  The curve count is rounded
+ * up to a multiple of 8 as the reference does (main.c:585-589).
  */
 #include "../../include/gecm.h"
 #include "calc_lite.h"
@@ -137,6 +138,9 @@ int main(int argc, char **argv)
     if (gpus > have) gpus = have;
     if (gpus > MAX_GPUS) gpus = MAX_GPUS;
     if (numcurves == 0 || B1 < 2 || B1 > 100000000ULL) { printf("need curves >= 1 and 2 <= B1 <= 1e8\n"); return 1; }
+    /* the reference runs whole vectors: curves are rounded up to a multiple of VECLEN = 8
+     * (main.c:585-589, ecm.c:1151), so "10 curves" writes 16 resume lines there and here */
+    numcurves = (numcurves + 7) / 8 * 8;
 
     printf("commencing parallel ecm on %s\n", ndec);                              /* main.c:503 */
     job_t jobs[MAX_GPUS];

@@ -51,3 +51,10 @@ def test_cli_expression_input_config1():
 def test_cli_usage():
     p = subprocess.run([EXE], capture_output=True, text=True)
     assert p.returncode == 1 and "usage: avx-ecm" in p.stdout
+
+
+def test_cli_rounds_curves_up_to_a_multiple_of_8():
+    """main.c:585-589 / ecm.c:1151: the reference runs whole 8-lane vectors; 10 curves -> 16 lines"""
+    c = S1["K1N_two_full_batches_b1_500"]          # N without small factors, sigma 100.., 16 lines in the fixture
+    out, save, res = _run([c["N"], 10, c["B1"], 1, c["B2"], c["sigma0"]])
+    assert save.splitlines() == c["save_lines"] and len(c["save_lines"]) == 16
