@@ -238,3 +238,188 @@ __device__ __forceinline__ void run_tape(const uint32_t *__restrict__ tape, uint
         cst.put(C);
     }
 }
+
+// ======================================================================================
+// Two lanes per curve ("split-coordinate" stage 1) — for batches that do not fill the chip.
+//
+// MI355X has 1024 SIMDs; with one curve per lane a batch of B curves is B/64 wavefronts, so below
+// 65536 curves some SIMDs have no wave at all, and between full rounds of 2 waves/SIMD (131072 curves)
+// the last round runs part-empty.  Stage 1 is one long dependent chain per curve, so the only way to
+// use the idle SIMDs is to split a curve.  The XZ formulas are two-way parallel at every level: in
+// vec_add (ecm.c:407-443)
+// U=(x1-z1)(x2+z2) | V=(x1+z1)(x2-z2), then (U+V)^2 | (U-V)^2, then *z3 | *x3; in vec_duplicate
+// (ecm.c:445-457) (x+z)^2 | (x-z)^2, then U*V | s*(U-V), then - | (s*w+V)*w.  So lane 2j holds the X
+// coordinate and lane 2j+1 the Z coordinate of curve j's points A, B, C; each stage is ONE multiply
+// executed by both lanes on their own operands, and the halves are exchanged with a DPP quad
+// permutation (v_mov_b32_dpp quad_perm:[1,0,3,2], no LDS, no memory).  A point addition is 3
+// multiply-times instead of 6, a doubling 3 instead of 5, with twice the waves for the same batch:
+// measured 1.83x the curves/s for batches <= 32768, equal at 65536, 3% slower at a full 131072
+// (the idle third multiply of a doubling and the exchanges) — tools/lanes_bench.py, DESIGN.md §5.
+// The field operations and their operands are exactly those of the one-lane-per-curve kernel, so
+// the results are the same integers.  The sign of each add/sub differs between the two lanes of a
+// pair; it is a per-lane select on the subtrahend (fe_addsub_lane), not a branch.
+template <int NL>
+__device__ __forceinline__ void fe_partner(Fe<NL> &r, const Fe<NL> &a)
+{
+#pragma unroll
+    for (int i = 0; i < NL; i++)
+        r.v[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)a.v[i], 0xB1 /* quad_perm:[1,0,3,2] */, 0xF, 0xF, true);
+}
+
+// r = x + y on lanes with neg == false, x - y + K on lanes with neg == true (limb-wise, lazy).
+template <int NL>
+__device__ __forceinline__ void fe_addsub_lane(Fe<NL> &r, const Fe<NL> &x, const Fe<NL> &y, bool neg,
+                                               const ModK<NL> &m)
+{
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        uint32_t t = neg ? m.kp[i] - y.v[i] : y.v[i];
+        r.v[i] = x.v[i] + t;
+    }
+    if (LazyPolicy<NL>::norm_sub) fe_weak_norm(r);
+}
+
+// own coordinate of P -> X lane: P.X + P.Z, Z lane: P.X - P.Z
+template <int NL>
+__device__ __forceinline__ void pair_sum_diff(Fe<NL> &r, const Fe<NL> &own, bool isZ, const ModK<NL> &m)
+{
+    Fe<NL> oth;
+    fe_partner(oth, own);
+    fe_addsub_lane(r, oth, own, isZ, m);
+}
+
+// own coordinate of P -> X lane: P.X - P.Z, Z lane: P.X + P.Z
+template <int NL>
+__device__ __forceinline__ void pair_diff_sum(Fe<NL> &r, const Fe<NL> &own, bool isZ, const ModK<NL> &m)
+{
+    Fe<NL> oth;
+    fe_partner(oth, own);
+    fe_addsub_lane(r, own, oth, !isZ, m);
+}
+
+// T = P1 + P2 with difference C: fB = pair_diff_sum(P1), fA = pair_sum_diff(P2).  ecm.c:417-440
+template <int NL>
+__device__ __forceinline__ void pair_add(Fe<NL> &T, const Fe<NL> &fB, const Fe<NL> &fA, const Fe<NL> &c, bool isZ,
+                                         const ModK<NL> &m)
+{
+    Fe<NL> w, t, e;
+    fe_mul(w, fB, fA, m);              // X lane: U = (x1-z1)(x2+z2)     Z lane: V = (x1+z1)(x2-z2)
+    fe_partner(t, w);
+    fe_addsub_lane(e, t, w, isZ, m);   // X lane: V + U                  Z lane: U - V
+    fe_sqr(e, e, m);
+    fe_partner(t, c);                  // X lane: C.Z                    Z lane: C.X
+    fe_mul(T, e, t, m);                // X lane: (U+V)^2 * z3           Z lane: (U-V)^2 * x3
+}
+
+// D = 2P: fA = pair_sum_diff(P), s4 = (A+2)/4 of this curve.  ecm.c:447-454
+template <int NL>
+__device__ __forceinline__ void pair_dup(Fe<NL> &D, const Fe<NL> &fA, const Fe<NL> &s4, bool isZ,
+                                         const ModK<NL> &m)
+{
+    Fe<NL> q, t, w, p1, p2, r1;
+    fe_sqr(q, fA, m);                  // X lane: U = (x+z)^2            Z lane: V = (x-z)^2
+    fe_partner(t, q);                  // X lane: V                      Z lane: U
+    fe_sub(w, t, q, m);                // Z lane: w = U - V              (X lane: unused)
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        p1.v[i] = isZ ? s4.v[i] : q.v[i];
+        p2.v[i] = isZ ? w.v[i] : t.v[i];
+    }
+    fe_mul(r1, p1, p2, m);             // X lane: X = U*V                Z lane: t = s*w
+    fe_add(t, r1, q);                  // Z lane: t + V
+    fe_mul(t, t, w, m);                // Z lane: Z = (t+V)*w            (X lane: idle multiply)
+#pragma unroll
+    for (int i = 0; i < NL; i++) D.v[i] = isZ ? t.v[i] : r1.v[i];
+}
+
+// run_tape for the split-coordinate layout: A, B, C are this lane's coordinate of prac()'s three
+// points.  Same tape, same renamings as run_tape above.
+template <int NL>
+__device__ __forceinline__ void run_tape_pair(const uint32_t *__restrict__ tape, uint32_t tape_len, Fe<NL> &A,
+                                              const uint32_t *__restrict__ S, size_t stride, uint32_t cidx,
+                                              bool isZ, const ModK<NL> &m)
+{
+    Fe<NL> B = A, C = A;
+    auto fetch = [&](uint32_t pc) -> uint32_t {
+        uint32_t w = tape[pc >> 2];
+        return __builtin_amdgcn_readfirstlane((w >> ((pc & 3u) * 8u)) & 0xffu);
+    };
+    uint32_t nxt = tape_len ? fetch(0) : GECM_OP_NOP;
+    for (uint32_t pc = 0; pc < tape_len; pc++) {
+        uint32_t op = nxt;
+        nxt = (pc + 1 < tape_len) ? fetch(pc + 1) : GECM_OP_NOP;
+        // rule 3: T = B + A (C); (B,T,C) <- (T,C,B)
+        while ((op & ~GECM_OP_SWAP) == (GECM_OP_STEP | GECM_OP_RULE3)) {
+            if (op & GECM_OP_SWAP) {
+                Fe<NL> t = A;
+                A = B;
+                B = t;
+            }
+            Fe<NL> fA, fB, T;
+            pair_diff_sum(fB, B, isZ, m);
+            pair_sum_diff(fA, A, isZ, m);
+            pair_add(T, fB, fA, C, isZ, m);
+            C = B;
+            B = T;
+            pc++;
+            op = nxt;
+            nxt = (pc + 1 < tape_len) ? fetch(pc + 1) : GECM_OP_NOP;
+        }
+        if (op == GECM_OP_NOP) continue;
+        const uint32_t rule = op & GECM_OP_RULE_MASK;
+        const bool is_step = op >= GECM_OP_STEP;
+        const bool do_add = op != GECM_OP_PRAC_BEGIN;
+        const bool do_dup = op != GECM_OP_PRAC_END;
+        if (is_step && (op & GECM_OP_SWAP)) {
+            Fe<NL> t = A;
+            A = B;
+            B = t;
+        }
+        if (is_step && rule == GECM_OP_RULE5) {
+            Fe<NL> t = B;
+            B = C;
+            C = t;
+        } else if (is_step && rule == GECM_OP_RULE9) {
+            Fe<NL> t = A;
+            A = B;
+            B = C;
+            C = t;
+        } else if (op == GECM_OP_PRAC_BEGIN) {
+            B = A;
+            C = A;
+        }
+        Fe<NL> T, D;
+        {
+            Fe<NL> fA;
+            pair_sum_diff(fA, A, isZ, m);
+            if (do_add) {
+                Fe<NL> fB;
+                pair_diff_sum(fB, B, isZ, m);
+                pair_add(T, fB, fA, C, isZ, m);
+            }
+            if (do_dup) {
+                Fe<NL> s4;
+                fe_load(s4, S, stride, cidx);
+                pair_dup(D, fA, s4, isZ, m);
+            }
+        }
+        if (op == GECM_OP_PRAC_END) {
+            A = T;
+        } else if (op == GECM_OP_PRAC_BEGIN) {
+            A = D;
+        } else if (rule == GECM_OP_RULE4) {
+            B = T;
+            A = D;
+        } else if (rule == GECM_OP_RULE5) {
+            Fe<NL> t = C;
+            C = T;
+            B = t;
+            A = D;
+        } else {
+            Fe<NL> oldA = C;
+            C = T;
+            B = D;
+            A = oldA;
+        }
+    }
+}

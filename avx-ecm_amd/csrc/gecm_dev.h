@@ -33,7 +33,11 @@ size_t gecm_dev_stride(gecm_dev *d);
 int gecm_dev_upload(gecm_dev *d, const uint32_t *X, const uint32_t *Z, const uint32_t *S);
 int gecm_dev_set_tape(gecm_dev *d, const uint8_t *tape, size_t len);
 /* stage 1: asynchronous on the context's stream; HIP events bracket the kernel */
-int gecm_dev_stage1(gecm_dev *d);
+/* lanes_per_curve: 1 = one curve per lane, 2 = X and Z of a curve on two adjacent lanes (for batches
+ * too small to fill the chip), 0 = let the device layer choose from the batch size and CU count */
+int gecm_dev_stage1(gecm_dev *d, int lanes_per_curve);
+int gecm_dev_auto_lanes(gecm_dev *d);
+int gecm_dev_last_lanes(gecm_dev *d);
 int gecm_dev_sync(gecm_dev *d);
 float gecm_dev_last_kernel_ms(gecm_dev *d);
 /* canonical Montgomery-form X, Z (what P holds after ecm_stage1 in the reference, modulo R) */

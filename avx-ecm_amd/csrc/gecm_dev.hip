@@ -50,6 +50,8 @@ struct gecm_dev {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_ms = 0.f;
     bool timed = false;
+    int cus = 0;          // compute units of the device (4 SIMDs each)
+    int last_lanes = 0;   // lanes per curve the last stage-1 launch used
 };
 
 extern "C" int gecm_dev_count(void)
@@ -87,8 +89,11 @@ extern "C" int gecm_dev_open(gecm_dev **out, int device, int nl, const uint32_t 
         return -2;
     }
     HIPCHK(hipSetDevice(device));
+    int cus = 0;
+    HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
     gecm_dev *d = new gecm_dev;
     d->device = device;
+    d->cus = cus;
     d->nl = nl;
     d->n.assign(n, n + nl);
     d->kp.assign(kp, kp + nl);
@@ -205,20 +210,47 @@ extern "C" int gecm_dev_set_tape(gecm_dev *d, const uint8_t *tape, size_t len)
     return 0;
 }
 
-extern "C" int gecm_dev_stage1(gecm_dev *d)
+/* Lanes per curve for this batch (tools/lanes_bench.py).  One curve per lane runs in
+ * rounds of 2 wavefronts on each SIMD (4 per CU): full = 128 curves x SIMDs.  It is the faster layout
+ * (by ~3%) only when its last round is nearly full; whenever that round would leave SIMDs idle or
+ * half-occupied, two lanes per curve — twice the wavefronts, each half as long — fills them:
+ * 1.83x below a quarter of `full`, 1.05x at half, 1.26x at three quarters.
+ * From 23 limbs up (>= 612-bit N) the split layout is the faster one at every batch size (all three
+ * points stay in registers instead of one being parked in LDS: +10% at 37 limbs, tools/lanes_sizes.py). */
+extern "C" int gecm_dev_auto_lanes(gecm_dev *d)
+{
+    if (d->nl >= 23) return 2;
+    const size_t full = (size_t)d->cus * 4 * 128;
+    const size_t r = d->stride % full;
+    return (r == 0 || r > full / 4 * 3) ? 1 : 2;
+}
+
+extern "C" int gecm_dev_last_lanes(gecm_dev *d) { return d->last_lanes; }
+
+extern "C" int gecm_dev_stage1(gecm_dev *d, int lanes_per_curve)
 {
     HIPCHK(hipSetDevice(d->device));
     if (!d->stride || !d->dTape) {
         g_err = "gecm_dev_stage1: no curves or no tape";
         return -2;
     }
+    if (lanes_per_curve == 0) lanes_per_curve = gecm_dev_auto_lanes(d);
+    if (lanes_per_curve != 1 && lanes_per_curve != 2) {
+        g_err = "gecm_dev_stage1: lanes per curve must be 0 (auto), 1 or 2";
+        return -2;
+    }
+    d->last_lanes = lanes_per_curve;
     gecm_modconst mc = modconst(d);
     HIPCHK(hipEventRecord(d->ev0, d->stream));
     switch (d->nl) {
 #define X(n)                                                                                     \
     case n:                                                                                      \
-        gecm_launch_stage1_##n(d->stream, &mc, d->dTape, (uint32_t)d->tape_len, d->dX, d->dZ,    \
-                               d->dS, d->stride);                                                \
+        if (lanes_per_curve == 2)                                                                \
+            gecm_launch_stage1_pair_##n(d->stream, &mc, d->dTape, (uint32_t)d->tape_len, d->dX,  \
+                                        d->dZ, d->dS, d->stride);                                \
+        else                                                                                     \
+            gecm_launch_stage1_##n(d->stream, &mc, d->dTape, (uint32_t)d->tape_len, d->dX,       \
+                                   d->dZ, d->dS, d->stride);                                     \
         break;
         GECM_NL_LIST(X)
 #undef X

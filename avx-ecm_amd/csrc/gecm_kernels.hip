@@ -47,6 +47,24 @@ k_stage1(const uint32_t *__restrict__ tape, uint32_t tape_len, uint32_t *__restr
     fe_store(Z, stride, idx, oz);
 }
 
+// Two lanes per curve (gecm_curve.hpp, "split-coordinate"): lane 2j works on X, lane 2j+1 on Z of
+// curve blockIdx.x*32 + j.  Chosen by the device layer for batches that leave SIMDs under-occupied.
+template <int NL>
+__global__ void __launch_bounds__(64, 2)
+k_stage1_pair(const uint32_t *__restrict__ tape, uint32_t tape_len, uint32_t *__restrict__ X,
+              uint32_t *__restrict__ Z, const uint32_t *__restrict__ S, size_t stride, ModArgs<NL> a)
+{
+    const uint32_t cidx = blockIdx.x * 32u + (threadIdx.x >> 1);
+    const bool isZ = (threadIdx.x & 1u) != 0;
+    uint32_t *mine = isZ ? Z : X;
+    Fe<NL> P;
+    fe_load(P, mine, stride, cidx);
+    run_tape_pair<NL>(tape, tape_len, P, S, stride, cidx, isZ, a.m);
+    Fe<NL> o;
+    fe_canonical_mont(o, P, a.one, a.m);
+    fe_store(mine, stride, cidx, o);
+}
+
 template <int NL>
 __global__ void __launch_bounds__(64)
 k_from_mont(const uint32_t *__restrict__ X, const uint32_t *__restrict__ Z, uint32_t *__restrict__ ox,
@@ -182,6 +200,14 @@ extern "C" void CAT(gecm_launch_stage1_, GECM_NL)(void *stream, const gecm_modco
 {
     hipLaunchKernelGGL(k_stage1<GECM_NL>, dim3((unsigned)(stride / 64)), dim3(64), 0, (hipStream_t)stream, tape,
                        tape_len, X, Z, S, stride, make_args<GECM_NL>(mc));
+}
+
+extern "C" void CAT(gecm_launch_stage1_pair_, GECM_NL)(void *stream, const gecm_modconst *mc, const uint32_t *tape,
+                                                        uint32_t tape_len, uint32_t *X, uint32_t *Z,
+                                                        const uint32_t *S, size_t stride)
+{
+    hipLaunchKernelGGL(k_stage1_pair<GECM_NL>, dim3((unsigned)(stride / 32)), dim3(64), 0, (hipStream_t)stream,
+                       tape, tape_len, X, Z, S, stride, make_args<GECM_NL>(mc));
 }
 
 extern "C" void CAT(gecm_launch_from_mont_, GECM_NL)(void *stream, const gecm_modconst *mc, const uint32_t *X,

@@ -66,6 +66,7 @@ struct gecm_ctx {
     int scan_valid[2];       /* the cached scan belongs to the current stage-1 / stage-2 result */
     uint64_t s2_ptadds, s2_numinv, s2_paired, s2_devinv;
     uint32_t s2_amin_last;
+    int lanes_per_curve;     /* 0 = auto, 1, 2 (gecm_set_lanes_per_curve) */
 };
 
 static int pick_nl(int nbits)
@@ -511,9 +512,18 @@ int gecm_stage1(gecm_ctx *c, uint64_t B1)
     c->have_acc = 0;
     c->s2_ready = 0;
     c->scan_valid[0] = c->scan_valid[1] = 0;
-    if (gecm_dev_stage1(c->dev)) { set_err("%s", gecm_dev_error()); return GECM_ERR_DEVICE; }
+    if (gecm_dev_stage1(c->dev, c->lanes_per_curve)) { set_err("%s", gecm_dev_error()); return GECM_ERR_DEVICE; }
     return GECM_OK;
 }
+
+int gecm_set_lanes_per_curve(gecm_ctx *c, int lanes)
+{
+    if (!c || lanes < 0 || lanes > 2) { set_err("gecm_set_lanes_per_curve: lanes must be 0 (auto), 1 or 2"); return GECM_ERR_ARG; }
+    c->lanes_per_curve = lanes;
+    return GECM_OK;
+}
+
+int gecm_get_lanes_per_curve(const gecm_ctx *c) { return c ? gecm_dev_last_lanes(c->dev) : GECM_ERR_ARG; }
 
 int gecm_sync(gecm_ctx *c)
 {

@@ -39,7 +39,8 @@ EXPORTS = ["gecm_last_error", "gecm_device_count", "gecm_version", "gecm_create"
            "gecm_vecaddmod", "gecm_vecsubmod", "gecm_vecaddsubmod", "gecm_build_curves",
            "gecm_upload_points", "gecm_stage1", "gecm_sync", "gecm_last_kernel_ms",
            "gecm_get_stage1_stats", "gecm_download_points", "gecm_download_points_plain",
-           "gecm_format_save_line", "gecm_stage1_factor"]
+           "gecm_format_save_line", "gecm_stage1_factor", "gecm_set_lanes_per_curve",
+           "gecm_get_lanes_per_curve"]
 
 _sig("gecm_last_error", c_char_p)
 _sig("gecm_device_count", c_int)
@@ -58,6 +59,8 @@ _sig("gecm_build_curves", c_int, c_void_p, ctypes.POINTER(c_u64), c_size_t)
 _sig("gecm_upload_points", c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t)
 _sig("gecm_stage1", c_int, c_void_p, c_u64)
 _sig("gecm_sync", c_int, c_void_p)
+_sig("gecm_set_lanes_per_curve", c_int, c_void_p, c_int)
+_sig("gecm_get_lanes_per_curve", c_int, c_void_p)
 _sig("gecm_last_kernel_ms", c_double, c_void_p)
 _sig("gecm_get_stage1_stats", c_int, c_void_p, ctypes.POINTER(Stage1Stats))
 _sig("gecm_download_points", c_int, c_void_p, c_void_p, c_void_p)
@@ -203,6 +206,14 @@ class Engine:
 
     def sync(self):
         _chk(lib.gecm_sync(self._h), "gecm_sync")
+
+    def set_lanes_per_curve(self, lanes):
+        """0 = chosen per launch from the batch size, 1 = curve per lane, 2 = X and Z on adjacent lanes"""
+        _chk(lib.gecm_set_lanes_per_curve(self._h, lanes), "gecm_set_lanes_per_curve")
+
+    def lanes_per_curve(self):
+        """what the last stage-1 launch used"""
+        return _chk(lib.gecm_get_lanes_per_curve(self._h), "gecm_get_lanes_per_curve")
 
     def last_kernel_ms(self):
         return lib.gecm_last_kernel_ms(self._h)

@@ -113,6 +113,7 @@ def main():
     ap.add_argument("--b1", type=int, default=1000000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-small-batch", action="store_true")
+    ap.add_argument("--lanes", type=int, default=0, help="lanes per curve in stage 1: 0 = library's choice, 1, 2")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; "
                     "gloo only to rehearse the multi-rank control flow on fewer GPUs than ranks)")
     ap.add_argument("--b2", type=int, default=0, help="also time one stage-2 pass to this B2 (reported separately)")
@@ -153,6 +154,8 @@ def main():
 
     found_log = []
 
+    eng.set_lanes_per_curve(a.lanes)
+
     def step():
         eng.stage1(a.b1, sync=True)
         kernel_ms.append(eng.last_kernel_ms())
@@ -178,6 +181,8 @@ def main():
 
     st = eng.stage1_stats()
     cfg = eng.cfg
+    lanes = eng.lanes_per_curve()
+    kname = ("k_stage1<%d>" if lanes == 1 else "k_stage1_pair<%d>") % cfg.dev_limbs
     stage2 = None
     if a.b2 > a.b1:
         # not part of the metric: one pass of the stage-2 continuation on the resident batch
@@ -191,14 +196,16 @@ def main():
                   "curves_with_factor": nf2}
     small = None
     if world == 1 and a.curves != 4096 and not a.no_small_batch:
-        # BASELINE.json configs[1] names a 4096-curve batch: 64 wavefronts, 3% of the 2048 resident
-        # wave slots of the device.  Measured separately (one pass) and reported next to `value`.
+        # BASELINE.json configs[1] names a 4096-curve batch: with one curve per lane that is 64
+        # wavefronts for 1024 SIMDs, so the library splits each curve over two lanes (128 wavefronts,
+        # each half as long).  Measured separately (one pass) and reported next to `value`.
         eng.build_curves(list(range(1000, 1000 + 4096)))
+        eng.set_lanes_per_curve(0)
         t1 = time.perf_counter()
         eng.stage1(a.b1, sync=True)
         t1 = time.perf_counter() - t1
         small = {"curves": 4096, "value": 4096 / t1, "unit": "curves/s", "ms_per_step": t1 * 1e3,
-                 "kernel_ms": eng.last_kernel_ms()}
+                 "kernel_ms": eng.last_kernel_ms(), "lanes_per_curve": eng.lanes_per_curve()}
     if rank == 0:
         total_curves = a.curves * world * a.steps
         value = total_curves / dt
@@ -209,12 +216,12 @@ def main():
         traffic = None
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
-            if pm.get("kernel") == "k_stage1<%d>" % cfg.dev_limbs and pm.get("curves") == a.curves and pm.get("B1") == a.b1:
+            if pm.get("kernel") == kname and pm.get("curves") == a.curves and pm.get("B1") == a.b1:
                 traffic = pm["hbm_bytes_per_launch_corrected"]
         except Exception:
             pass
         roof = {
-            "bound": "valu", "kernel": "k_stage1<%d>" % cfg.dev_limbs,
+            "bound": "valu", "kernel": kname,
             "achieved": achieved / 1e12, "peak": PEAK_MAD_PER_S / 1e12, "unit": "Tmad/s (v_mad_u64_u32 lane-ops)",
             "frac": achieved / PEAK_MAD_PER_S, "traffic": traffic,
             "traffic_note": "HBM bytes per launch from rocprofv3 PMC passes of this command (profiles/), FETCH_SIZE x2 "
@@ -236,7 +243,7 @@ def main():
                                    "wavefronts on each of the 1024 SIMDs), %d-bit random odd N (seed %d), B1=%d, "
                                    "sigma=1000.., stage 1 + device factor scan; reference limb format 52-bit NWORDS=%d"
                                    % (a.curves, a.curves // 4096, a.bits, a.bits, a.b1, cfg.nwords),
-                       "curves_per_gpu": a.curves, "bits": a.bits, "B1": a.b1,
+                       "curves_per_gpu": a.curves, "bits": a.bits, "B1": a.b1, "lanes_per_curve": lanes,
                        "curves_with_factor_last_step": found_log[-1][0],
                        "parallelism": "curve batch split across %d GPU(s) on the host, no data-path collective, "
                                       "1 all-reduce (RCCL) of the found record per step" % world},

@@ -93,6 +93,16 @@ int gecm_upload_points(gecm_ctx *ctx, const void *X, const void *Z, const void *
  * the launch; gecm_sync waits.  B1 <= 10^8 (one prime range, ecm.c:1209-1234).                */
 int gecm_stage1(gecm_ctx *ctx, uint64_t B1);
 int gecm_sync(gecm_ctx *ctx);
+/* How stage 1 maps curves to lanes.  1 = one curve per lane (64 per wavefront): the throughput layout,
+ * full speed from 2 wavefronts per SIMD, i.e. 128 x (4 x CUs) = 131072 curves on MI355X.  2 = the X and
+ * the Z coordinate of a curve on two adjacent lanes (32 curves per wavefront): each point operation's
+ * independent halves (ecm.c:417-440, 447-454) run side by side, so a curve finishes in half the time
+ * and a batch fills the chip at half the size (1.83x the curves/s up to 32768 curves on MI355X).
+ * 0 (default) = chosen per launch: 1 when the batch's last round of 128 x 4 x CUs curves is more than
+ * three quarters full and N is below 612 bits, else 2.  Results are identical.
+ * gecm_get_lanes_per_curve returns what the last gecm_stage1 launch used (0 before the first). */
+int gecm_set_lanes_per_curve(gecm_ctx *ctx, int lanes);
+int gecm_get_lanes_per_curve(const gecm_ctx *ctx);
 /* milliseconds of the last stage-1 kernel, from HIP events on the context's stream */
 double gecm_last_kernel_ms(const gecm_ctx *ctx);
 

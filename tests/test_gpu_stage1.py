@@ -19,13 +19,17 @@ def _n_of(case):
     return int(line.split("N=0x")[1].split(";")[0], 16)
 
 
-def _run(case, b1=None):
+def _run(case, b1=None, lanes=1):
+    """lanes: 1 = one curve per lane (the throughput kernel), 2 = X and Z of a curve on adjacent lanes
+    (what the library picks by itself for batches this small) — include/gecm.h gecm_set_lanes_per_curve"""
     import pyecm
     n = _n_of(case)
     eng = pyecm.Engine(n, digitbits=case["digitbits"])
     sig = [int(l.split("SIGMA=")[1].split(";")[0]) for l in case["save_lines"]]
     eng.build_curves(sig)
+    eng.set_lanes_per_curve(lanes)
     eng.stage1(b1 or case["B1"])
+    assert eng.lanes_per_curve() == lanes
     lines = [l.rstrip("\n") for l in eng.save_lines()]
     st = eng.stage1_stats()
     facs = [eng.stage1_factor(k) for k in range(len(sig))]
@@ -38,9 +42,10 @@ SMALL = [c for c in CASES if c["B1"] <= 100000]
 BIG = [c for c in CASES if c["B1"] > 100000]
 
 
+@pytest.mark.parametrize("lanes", [1, 2])
 @pytest.mark.parametrize("case", SMALL, ids=[c["name"] for c in SMALL])
-def test_stage1_save_lines_small(case):
-    lines, st, facs, cfg = _run(case)
+def test_stage1_save_lines_small(case, lanes):
+    lines, st, facs, cfg = _run(case, lanes=lanes)
     assert cfg.nwords == case["nwords"] and cfg.maxbits == case["maxbits"]
     assert st.ptadds == case["ptadds"] and st.ptdups == case["ptdups"]
     assert lines == case["save_lines"]
@@ -51,6 +56,34 @@ def test_stage1_save_lines_b1_1e6(case):
     lines, st, facs, cfg = _run(case)
     assert st.ptadds == 1980817 and st.ptdups == 217929
     assert lines == case["save_lines"]
+
+
+BIG2 = [c for c in BIG if c["name"] in ("K1", "n623_b1_1000000", "config1_fib791")]
+
+
+@pytest.mark.parametrize("case", BIG2, ids=[c["name"] for c in BIG2])
+def test_stage1_save_lines_b1_1e6_two_lanes_per_curve(case):
+    lines, st, facs, cfg = _run(case, lanes=2)
+    assert lines == case["save_lines"]
+
+
+def test_lanes_per_curve_is_chosen_from_the_batch_size():
+    """auto mode: two lanes per curve unless the batch fills whole rounds of 2 wavefronts per SIMD (256 CUs)"""
+    import pyecm
+    case = next(c for c in CASES if c["name"] == "K1N_two_full_batches_b1_500")
+    eng = pyecm.Engine(_n_of(case), digitbits=52)
+    assert eng.lanes_per_curve() == 0
+    eng.build_curves(list(range(100, 116)))
+    eng.stage1(500)
+    assert eng.lanes_per_curve() == 2
+    small = [l.rstrip("\n") for l in eng.save_lines()]
+    eng.build_curves(list(range(100, 100 + 131072)))     # a full round of 2 wavefronts on each of 1024 SIMDs
+    eng.stage1(500)
+    assert eng.lanes_per_curve() == 1
+    assert [l.rstrip("\n") for l in eng.save_lines()[:16]] == small == case["save_lines"]
+    with pytest.raises(pyecm.GecmError):
+        eng.set_lanes_per_curve(3)
+    eng.close()
 
 
 def test_stage1_factors_match_reference_results():

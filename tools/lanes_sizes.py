@@ -1,0 +1,29 @@
+"""Full-batch stage-1 kernel time, one curve per lane vs two lanes per curve, for every limb count.
+usage: python tools/lanes_sizes.py [B1] [batch]   (needs a GPU)"""
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "avx-ecm_amd"))
+import pyecm  # noqa: E402
+
+b1 = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
+batch = int(sys.argv[2]) if len(sys.argv) > 2 else 131072
+for nl in (8, 10, 12, 14, 15, 17, 19, 21, 23, 26, 28, 30, 32, 34, 37):
+    bits = 28 * nl - 5
+    n = (1 << bits) - 1
+    while any(n % p == 0 for p in (3, 5, 7, 11, 13)):
+        n -= 2
+    eng = pyecm.Engine(n, digitbits=52)
+    assert eng.cfg.dev_limbs == nl, (eng.cfg.dev_limbs, nl)
+    eng.build_curves(list(range(1000, 1000 + batch)))
+    row = []
+    for lanes in (1, 2):
+        eng.set_lanes_per_curve(lanes)
+        best = 1e30
+        for _ in range(2):
+            eng.stage1(b1)
+            best = min(best, eng.last_kernel_ms())
+        row.append(best)
+    print("NL %2d (%4d bits) batch %d  lanes=1 %8.1f ms  lanes=2 %8.1f ms  ratio %.3f"
+          % (nl, bits, batch, row[0], row[1], row[0] / row[1]), flush=True)
+    eng.close()
