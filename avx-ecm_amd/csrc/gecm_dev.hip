@@ -215,11 +215,12 @@ extern "C" int gecm_dev_set_tape(gecm_dev *d, const uint8_t *tape, size_t len)
  * (by ~3%) only when its last round is nearly full; whenever that round would leave SIMDs idle or
  * half-occupied, two lanes per curve — twice the wavefronts, each half as long — fills them:
  * 1.83x below a quarter of `full`, 1.05x at half, 1.26x at three quarters.
- * From 23 limbs up (>= 612-bit N) the split layout is the faster one at every batch size (all three
- * points stay in registers instead of one being parked in LDS: +10% at 37 limbs, tools/lanes_sizes.py). */
+ * From 26 limbs up (> 640-bit N) the split layout is the faster one at every batch size (all three
+ * points stay in registers instead of one being parked in LDS: +1.5% at 26 limbs, +4% at 30, +10% at 37;
+ * equal at 23 — tools/lanes_sizes.py, interleaved runs). */
 extern "C" int gecm_dev_auto_lanes(gecm_dev *d)
 {
-    if (d->nl >= 23) return 2;
+    if (d->nl >= 26) return 2;
     const size_t full = (size_t)d->cus * 4 * 128;
     const size_t r = d->stride % full;
     return (r == 0 || r > full / 4 * 3) ? 1 : 2;

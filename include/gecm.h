@@ -99,7 +99,7 @@ int gecm_sync(gecm_ctx *ctx);
  * independent halves (ecm.c:417-440, 447-454) run side by side, so a curve finishes in half the time
  * and a batch fills the chip at half the size (1.83x the curves/s up to 32768 curves on MI355X).
  * 0 (default) = chosen per launch: 1 when the batch's last round of 128 x 4 x CUs curves is more than
- * three quarters full and N is below 612 bits, else 2.  Results are identical.
+ * three quarters full and N is at most 639 bits, else 2.  Results are identical.
  * gecm_get_lanes_per_curve returns what the last gecm_stage1 launch used (0 before the first). */
 int gecm_set_lanes_per_curve(gecm_ctx *ctx, int lanes);
 int gecm_get_lanes_per_curve(const gecm_ctx *ctx);
