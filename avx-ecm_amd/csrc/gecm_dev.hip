@@ -3,6 +3,7 @@
 #include "gecm_dev.h"
 #include "gecm_launch.h"
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -46,6 +47,7 @@ struct gecm_dev {
     uint32_t *dPa = nullptr, *dSteps = nullptr, *dFlags = nullptr;
     size_t flags_cap = 0;
     size_t s2_npb = 0, s2_G = 0, s2_ring = 0, s2_stride = 0, steps_cap = 0, keep_cap = 0;
+    uint32_t s2_slices = 1;   // stage-2 accumulators per curve (pair-walk slices), see gecm_dev_s2_init
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_ms = 0.f;
@@ -346,7 +348,7 @@ extern "C" size_t gecm_dev_s2_bytes(int nl, size_t ncurves, uint32_t npb, uint32
 {
     size_t stride = (ncurves + 63) / 64 * 64;
     size_t coord = (size_t)nl * stride * 4;
-    return coord * ((size_t)npb + 3 * GECM_S2_BLK + 2 + 2 + 2 * ((size_t)G + 2) + (size_t)G + (size_t)ring_size);
+    return coord * ((size_t)npb + 3 * GECM_S2_BLK + 2 + 1 + 32 /* acc slices, upper bound */ + 2 * ((size_t)G + 2) + (size_t)G + (size_t)ring_size);
 }
 
 extern "C" int gecm_dev_s2_init(gecm_dev *d, const uint32_t *keep, size_t keep_words, uint32_t umax, uint32_t D,
@@ -363,7 +365,19 @@ extern "C" int gecm_dev_s2_init(gecm_dev *d, const uint32_t *keep, size_t keep_w
         HIPCHK(hipMalloc(&d->dPbX, coord * npb));
         HIPCHK(hipMalloc(&d->dBlk, coord * 3 * GECM_S2_BLK));    // bx, bz, bp: S2_BLK entries each
         HIPCHK(hipMalloc(&d->dPd, coord * 2));
-        HIPCHK(hipMalloc(&d->dAcc, coord));
+        // The pair walk is a product, so a batch that cannot fill the chip with one wavefront per 64
+        // curves walks each run of pairs in `slices` parts (one more grid dimension, one accumulator
+        // each) until there are 2 wavefronts per SIMD; slice 0 is the accumulator everyone else sees.
+        {
+            const size_t waves = d->stride / 64, want = (size_t)d->cus * 4 * 2;
+            size_t p = waves ? want / waves : 1;
+            d->s2_slices = (uint32_t)(p < 1 ? 1 : p > 32 ? 32 : p);
+            if (const char *e = getenv("GECM_S2_SLICES")) {      // measurement knob (tools/s2_small.py)
+                const long v = strtol(e, nullptr, 10);
+                if (v >= 1 && v <= 32) d->s2_slices = (uint32_t)v;
+            }
+        }
+        HIPCHK(hipMalloc(&d->dAcc, coord * d->s2_slices));
         HIPCHK(hipMalloc(&d->dFail, coord));
         // giant steps: gx, gz (G+2 entries each), gp (G), ring (ring_size)
         HIPCHK(hipMalloc(&d->dPa, coord * (2 * ((size_t)G + 2) + (size_t)G + (size_t)ring_size)));
@@ -391,6 +405,7 @@ extern "C" int gecm_dev_s2_init(gecm_dev *d, const uint32_t *keep, size_t keep_w
 #define X(n)                                             \
     case n:                                              \
         gecm_launch_s2_init_##n(d->stream, &mc, &a);     \
+        if (d->s2_slices > 1) gecm_launch_s2_acc_init_##n(d->stream, &mc, d->dAcc, d->s2_slices, d->stride); \
         break;
         GECM_NL_LIST(X)
 #undef X
@@ -425,6 +440,7 @@ extern "C" int gecm_dev_s2_pair(gecm_dev *d, const uint32_t *steps, uint32_t nst
     a.gx = d->dPa; a.gz = a.gx + cw * ((size_t)G + 2); a.gp = a.gz + cw * ((size_t)G + 2); a.ring = a.gp + cw * (size_t)G;
     a.acc = d->dAcc; a.fail = d->dFail; a.steps = d->dSteps; a.host_steps = steps;
     a.nsteps = nsteps; a.D = D; a.G = G; a.ring_size = ring_size; a.A0 = A0; a.stride = d->stride;
+    a.slices = d->s2_slices;
     gecm_modconst mc = modconst(d);
     HIPCHK(hipEventRecord(d->ev0, d->stream));
     switch (d->nl) {

@@ -157,7 +157,19 @@ __global__ void __launch_bounds__(64, 2) k_s2_gen(S2PairArgs a, uint32_t first_a
 template <int NL>
 __global__ void __launch_bounds__(64, 2) k_s2_pairs(S2PairArgs a, uint32_t first, uint32_t count, S2Const<NL> k)
 {
-    s2_pairs<NL>(a, first, count, k, blockIdx.x * 64u + threadIdx.x);
+    // gridDim.y slices of the segment, one accumulator each (see s2_pairs)
+    const uint32_t per = (count + gridDim.y - 1) / gridDim.y;
+    const uint32_t off = blockIdx.y * per;
+    if (off >= count) return;
+    const uint32_t n = count - off < per ? count - off : per;
+    s2_pairs<NL>(a, first + off, n, k, blockIdx.x * 64u + threadIdx.x, a.acc + (size_t)blockIdx.y * NL * a.stride);
+}
+
+template <int NL>
+__global__ void __launch_bounds__(64, 2) k_s2_merge(uint32_t *acc, uint32_t slices, size_t stride, int init_only,
+                                                    S2Const<NL> k)
+{
+    s2_merge<NL>(acc, slices, stride, init_only != 0, k, blockIdx.x * 64u + threadIdx.x);
 }
 
 #endif
@@ -249,6 +261,7 @@ extern "C" void CAT(gecm_launch_s2_pair_, GECM_NL)(void *stream, const gecm_modc
     // the tape on the host decides the launch sequence: one k_s2_gen per "generate" mark, one
     // k_s2_pairs per run of pairs between marks (~84 + 84 launches per 1e8 range)
     const dim3 grid((unsigned)(h->stride / 64)), block(64);
+    const dim3 pgrid((unsigned)(h->stride / 64), h->slices ? h->slices : 1);
     const S2Const<GECM_NL> k = make_s2<GECM_NL>(mc);
     uint32_t generated = 0, i = 0;
     while (i < h->nsteps) {
@@ -260,10 +273,19 @@ extern "C" void CAT(gecm_launch_s2_pair_, GECM_NL)(void *stream, const gecm_modc
         } else {
             uint32_t j = i;
             while (j < h->nsteps && h->host_steps[2 * j] != S2_STEP_GEN) j++;
-            hipLaunchKernelGGL(k_s2_pairs<GECM_NL>, grid, block, 0, (hipStream_t)stream, a, i, j - i, k);
+            hipLaunchKernelGGL(k_s2_pairs<GECM_NL>, pgrid, block, 0, (hipStream_t)stream, a, i, j - i, k);
             i = j;
         }
     }
+    if (h->slices > 1)
+        hipLaunchKernelGGL(k_s2_merge<GECM_NL>, grid, block, 0, (hipStream_t)stream, h->acc, h->slices, h->stride, 0, k);
+}
+
+extern "C" void CAT(gecm_launch_s2_acc_init_, GECM_NL)(void *stream, const gecm_modconst *mc, uint32_t *acc,
+                                                        uint32_t slices, size_t stride)
+{
+    hipLaunchKernelGGL(k_s2_merge<GECM_NL>, dim3((unsigned)(stride / 64)), dim3(64), 0, (hipStream_t)stream, acc, slices,
+                       stride, 1, make_s2<GECM_NL>(mc));
 }
 #endif
 #if GECM_HAS_PART(1)

@@ -34,6 +34,7 @@ typedef struct {
     const uint32_t *steps;        /* device copy of the tape */
     const uint32_t *host_steps;   /* host copy: the launcher splits it at the "generate" marks */
     uint32_t nsteps, D, G, ring_size;
+    uint32_t slices;              /* accumulators per curve: each run of pairs is cut into this many slices */
     uint64_t A0;
     size_t stride;
 } gecm_s2_pair_args;
@@ -52,6 +53,8 @@ typedef struct {
                              const uint32_t *fix);                                                        \
     void gecm_launch_s2_init_##nl(void *stream, const gecm_modconst *mc, const gecm_s2_init_args *h);     \
     void gecm_launch_s2_pair_##nl(void *stream, const gecm_modconst *mc, const gecm_s2_pair_args *h);     \
+    void gecm_launch_s2_acc_init_##nl(void *stream, const gecm_modconst *mc, uint32_t *acc,               \
+                                      uint32_t slices, size_t stride);                                    \
     void gecm_launch_gcd_scan_##nl(void *stream, const gecm_modconst *mc, const uint32_t *V, uint32_t *G, \
                                    uint32_t *flags, size_t stride);
 GECM_NL_LIST(GECM_DECL)

@@ -417,15 +417,19 @@ __device__ __forceinline__ void giant_chunk(const S2PairArgs &a, uint32_t first_
 
 // The pair walk of ecm_stage2_pair (ecm.c:2448-2533) over tape entries [first, first+count): every
 // entry is a pair (ring slot, table index); "generate" marks are separate launches of giant_chunk.
+// The product over the pairs is order-independent, so a segment may be cut into slices walked by
+// different wavefronts into separate accumulators (accbuf = this slice's accumulator, [limb][curve]);
+// s2_merge multiplies them together.  Each slice starts from `one` = R mod N, so the merged Montgomery
+// product one * prod(d_i) * R^-n is the same residue as the reference's single running accumulator.
 template <int NL>
 __device__ __forceinline__ void s2_pairs(const S2PairArgs &a, uint32_t first, uint32_t count, const S2Const<NL> &k,
-                                         uint32_t idx)
+                                         uint32_t idx, uint32_t *__restrict__ accbuf)
 {
     const ModK<NL> &m = k.m;
     const size_t stride = a.stride;
     if (count == 0) return;
     Fe<NL> acc;
-    fe_load(acc, a.acc, stride, idx);
+    fe_load(acc, accbuf, stride, idx);
     // Lookahead: the baby-step rows of the next DEPTH pairs are in flight while the current pair is
     // multiplied, so HBM latency (2-3 us under load) hides behind the arithmetic.  The host sorts the
     // pairs of a segment by giant step (the product is order-independent), so the ring row is
@@ -480,5 +484,29 @@ __device__ __forceinline__ void s2_pairs(const S2PairArgs &a, uint32_t first, ui
     }
     Fe<NL> c;
     fe_canonical_mont(c, acc, k.one, m);
-    fe_store(a.acc, stride, idx, c);
+    fe_store(accbuf, stride, idx, c);
+}
+
+// acc[0] <- product of the `slices` accumulators (skipped when init_only); acc[1..] <- one.
+template <int NL>
+__device__ __forceinline__ void s2_merge(uint32_t *__restrict__ acc, uint32_t slices, size_t stride, bool init_only,
+                                         const S2Const<NL> &k, uint32_t idx)
+{
+    const size_t slice_words = (size_t)NL * stride;
+    Fe<NL> r;
+    if (!init_only) fe_load(r, acc, stride, idx);
+    for (uint32_t p = 1; p < slices; p++) {
+        uint32_t *sp = acc + p * slice_words;
+        if (!init_only) {
+            Fe<NL> t;
+            fe_load(t, sp, stride, idx);
+            fe_mul(r, r, t, k.m);
+        }
+        fe_store(sp, stride, idx, k.one);
+    }
+    if (!init_only) {
+        Fe<NL> c;
+        fe_canonical_mont(c, r, k.one, k.m);
+        fe_store(acc, stride, idx, c);
+    }
 }
