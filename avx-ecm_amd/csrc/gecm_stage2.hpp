@@ -421,6 +421,9 @@ __device__ __forceinline__ void giant_chunk(const S2PairArgs &a, uint32_t first_
 // different wavefronts into separate accumulators (accbuf = this slice's accumulator, [limb][curve]);
 // s2_merge multiplies them together.  Each slice starts from `one` = R mod N, so the merged Montgomery
 // product one * prod(d_i) * R^-n is the same residue as the reference's single running accumulator.
+#ifndef GECM_S2_DEPTH
+#define GECM_S2_DEPTH 4
+#endif
 template <int NL>
 __device__ __forceinline__ void s2_pairs(const S2PairArgs &a, uint32_t first, uint32_t count, const S2Const<NL> &k,
                                          uint32_t idx, uint32_t *__restrict__ accbuf)
@@ -437,7 +440,7 @@ __device__ __forceinline__ void s2_pairs(const S2PairArgs &a, uint32_t first, ui
     // baby-step table comes from HBM instead of two rows (the walk is HBM-bound otherwise:
     // 2*60 B x 131,072 curves x 3.0 M pairs = 47 TB at B2 = 1e8).
     const uint32_t *st = a.steps + 2 * (size_t)first;
-    constexpr int DEPTH = 4;                          // table rows in flight per lane
+    constexpr int DEPTH = GECM_S2_DEPTH;              // table rows in flight per lane
     Fe<NL> x, yq[DEPTH];
     // tape words are fetched one group ahead too (scalar loads): cs = giant-step slots of the current
     // group of DEPTH pairs, rb = table indices of the group after it (the rows to request next)

@@ -116,13 +116,14 @@ int main(int argc, char **argv)
     }
     double t_start = now();
     printf("starting process %d\n", (int)getpid());                               /* main.c:391 */
-    mpl_t N;
-    if (calc_lite(&N, argv[1]) || mpl_cmp_u64(&N, 3) < 0 || !mpl_is_odd(&N)) {
+    /* main.c:393-457: evaluate the expression, recognise Cunningham-type inputs, strip algebraic factors */
+    static char ndec[MPL_MAXL * 10 + 16], prep_log[65536];
+    gecm_input_info inf;
+    if (gecm_prepare_input(argv[1], 52, ndec, sizeof ndec, &inf, prep_log, sizeof prep_log)) {
+        fputs(prep_log, stdout);
         printf("input must evaluate to an odd integer >= 3 (operators + - * / %% ^ ! # fib() luc())\n");
         return 1;
     }
-    static char ndec[MPL_MAXL * 10 + 16];
-    mpl_get_dec(ndec, &N);
     size_t numcurves = strtoul(argv[2], NULL, 10);
     uint64_t B1 = strtoull(argv[3], NULL, 10);
     uint64_t B2 = 100ULL * B1;                                                    /* main.c:462 */
@@ -142,7 +143,10 @@ int main(int argc, char **argv)
      * (main.c:585-589, ecm.c:1151), so "10 curves" writes 16 resume lines there and here */
     numcurves = (numcurves + 7) / 8 * 8;
 
-    printf("commencing parallel ecm on %s\n", ndec);                              /* main.c:503 */
+    fputs(prep_log, stdout);          /* "gen: ...", "removing algebraic ...", "commencing parallel ecm on ..." */
+    if (inf.ref_special_reduction)
+        printf("Input divides 2^%d %c %d: no special reduction on the GPU, REDC on the %d-bit cofactor "
+               "(residues = the reference's modulo N)\n", inf.k, inf.form > 0 ? '-' : '+', inf.form, inf.nbits);
     job_t jobs[MAX_GPUS];
     memset(jobs, 0, sizeof jobs);
     for (int g = 0; g < gpus; g++) {
@@ -209,12 +213,12 @@ int main(int argc, char **argv)
                 if (r == 1) {
                     size_t curve = done + jobs[g].first + k;
                     printf("\nfound %s%d factor %s in stage 1 (B1 = %lu): thread %d, vec %zu, sigma %lu\n",
-                           prp ? "PRP" : "C", (int)strlen(fac), fac, (unsigned long)B1, g, k,
+                           prp ? "PRP" : "C", gecm_sizeinbase10(fac), fac, (unsigned long)B1, g, k,
                            (unsigned long)jobs[g].sigma[k]);
                     FILE *out = fopen("ecm_results.txt", "a");
                     if (out) {
                         fprintf(out, "\nfound %s%d factor %s in stage 1 (B1 = %lu): curve %zu, thread %d, vec %zu, sigma %lu\n",
-                                prp ? "PRP" : "C", (int)strlen(fac), fac, (unsigned long)B1, curve, g, k,
+                                prp ? "PRP" : "C", gecm_sizeinbase10(fac), fac, (unsigned long)B1, curve, g, k,
                                 (unsigned long)jobs[g].sigma[k]);
                         fclose(out);
                     }
@@ -241,12 +245,12 @@ int main(int argc, char **argv)
                     if (gecm_curve_flag(jobs[g].ctx, 2, k) && gecm_stage2_factor(jobs[g].ctx, k, fac, sizeof fac, &prp) == 1) {
                         size_t curve = done + jobs[g].first + k;
                         printf("\nfound %s%d factor %s in stage 2 (B2 = %lu): thread %d, vec %zu, sigma %lu\n",
-                               prp ? "PRP" : "C", (int)strlen(fac), fac, (unsigned long)B2, g, k,
+                               prp ? "PRP" : "C", gecm_sizeinbase10(fac), fac, (unsigned long)B2, g, k,
                                (unsigned long)jobs[g].sigma[k]);
                         FILE *out = fopen("ecm_results.txt", "a");
                         if (out) {
                             fprintf(out, "\nfound %s%d factor %s in stage 2 (B2 = %lu): curve %zu, thread %d, vec %zu, sigma %lu\n",
-                                    prp ? "PRP" : "C", (int)strlen(fac), fac, (unsigned long)B2, curve, g, k,
+                                    prp ? "PRP" : "C", gecm_sizeinbase10(fac), fac, (unsigned long)B2, curve, g, k,
                                     (unsigned long)jobs[g].sigma[k]);
                             fclose(out);
                         }

@@ -444,3 +444,13 @@ void mpl_from_limbs64(mpl_t *r, const uint64_t *in, size_t stride, int count, in
     norm(&t);
     *r = t;
 }
+
+/* mpz_sizeinbase(a, 10) of GMP 6.x (MPN_SIZEINBASE with mp_bases[10].logb2 = floor(2^64 log10 2)):
+ * the high word of (logb2 + 1) * bits, plus one.  The reference prints factor sizes with it
+ * (ecm.c:1346, 1494; main.c:455), so "C13" can label a 12-digit factor. */
+int mpl_sizeinbase10(const mpl_t *a)
+{
+    if (mpl_is_zero(a)) return 1;
+    const unsigned __int128 p = (unsigned __int128)(0x4d104d427de7fbccULL + 1) * (unsigned)mpl_bits(a);
+    return (int)(uint64_t)(p >> 64) + 1;
+}

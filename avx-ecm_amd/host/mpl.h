@@ -27,6 +27,8 @@ int mpl_set_str(mpl_t *r, const char *s);       /* decimal, or hex with 0x prefi
 int mpl_get_hex(char *buf, const mpl_t *a);     /* lower case, no prefix, "0" for zero (as %Zx) */
 int mpl_get_dec(char *buf, const mpl_t *a);
 int mpl_bits(const mpl_t *a);
+/* what GMP's mpz_sizeinbase(a, 10) returns: floor(bits * log10(2)) + 1, exact or one too large; 1 for zero */
+int mpl_sizeinbase10(const mpl_t *a);
 int mpl_is_zero(const mpl_t *a);
 int mpl_is_odd(const mpl_t *a);
 int mpl_cmp(const mpl_t *a, const mpl_t *b);

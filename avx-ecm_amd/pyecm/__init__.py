@@ -91,7 +91,7 @@ _sig("gecm_download_acc", c_int, c_void_p, c_void_p)
 _sig("gecm_stage2_factor", c_int, c_void_p, c_size_t, c_char_p, c_size_t, ctypes.POINTER(c_int))
 _sig("gecm_scan_factors", c_int, c_void_p, c_int, ctypes.POINTER(c_size_t))
 _sig("gecm_curve_flag", c_int, c_void_p, c_int, c_size_t)
-EXPORTS += ["gecm_scan_factors", "gecm_curve_flag"]
+EXPORTS += ["gecm_scan_factors", "gecm_curve_flag", "gecm_prepare_input", "gecm_sizeinbase10"]
 EXPORTS += ["gecm_stage2_init", "gecm_pair_primes", "gecm_pairmap_release", "gecm_stage2_pair", "gecm_stage2",
             "gecm_get_stage2_stats", "gecm_download_acc", "gecm_stage2_factor"]
 

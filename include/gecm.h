@@ -88,6 +88,30 @@ int gecm_build_curves(gecm_ctx *ctx, const uint64_t *sigma, size_t batch);
  * Montgomery radix), e.g. the output of the reference's own build_one_curve.                 */
 int gecm_upload_points(gecm_ctx *ctx, const void *X, const void *Z, const void *s, size_t batch);
 
+/* ---- input preparation (main.c:393-527) -----------------------------------------------------
+ * What the reference's main() does to its first argument before any curve is built: evaluate the
+ * expression (calc.c), recognise N | 2^k - 1, N | 2^k + 1 or 2^k = c (mod N) with c below one limb
+ * (main.c:405-441), and for the first two replace N by gcd(N, primitive part of 2^k -/+ 1)
+ * (find_primitive_factor, main.c:187-352, 445-457).  n_dec receives the decimal N the run is made on;
+ * log receives the lines the reference prints on the way ("gen: ...", "removing algebraic ...",
+ * "commencing parallel ecm on ...", "Mersenne input ... determined to be faster by REDC"), byte for byte.
+ * libgecm always multiplies by REDC modulo N.  When the reference would instead fold modulo 2^k -/+ c
+ * (ref_special_reduction = 1; vecarith52.c:284-2436) its save lines hold residues modulo 2^k -/+ c;
+ * libgecm's are those residues reduced modulo N (DESIGN.md §9 has the one exception found).           */
+typedef struct {
+    int form;                   /* the reference's isMersenne: 0, +1 (2^k - 1), -1 (2^k + 1), else c of 2^k - c */
+    int k;
+    uint64_t c;
+    int nbits;                  /* bit length of the prepared N */
+    int ref_special_reduction;  /* 1 = the reference would not use REDC for this input (main.c:505-527) */
+} gecm_input_info;
+int gecm_prepare_input(const char *expr, int digitbits, char *n_dec, size_t n_len, gecm_input_info *info,
+                       char *log, size_t loglen);
+/* The size the reference prints next to a factor ("found PRP45 factor ...", ecm.c:1346-1366, 1494-1520) is
+ * mpz_sizeinbase(f, 10) = floor(bits * log10 2) + 1, which is the digit count or one more (a 12-digit
+ * factor of 40 bits is labelled C13).  This returns that number for a decimal string.                 */
+int gecm_sizeinbase10(const char *dec);
+
 /* ---- L1 phase 1: stage 1 (ecm_stage1, ecm.c:1806-1854) -------------------------------------
  * P <- [prod of prime powers < B1] P for every curve of the batch.  Asynchronous: returns after
  * the launch; gecm_sync waits.  B1 <= 10^8 (one prime range, ecm.c:1209-1234).                */

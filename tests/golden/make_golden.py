@@ -9,13 +9,18 @@ into oracle/_ref/).  The fixtures are data (inputs + outputs); no reference sour
   l0.json     : per-operator vectors (a, b, N -> mulmod, sqrmod, addmod, submod, addsub) from
                 the reference's vecarith52.c / vecarith.c via oracle/ref_l0_harness.c
 
-usage: python tests/golden/make_golden.py [--only stage1|l0] [--quick]
+  inputs.json : Cunningham-type command-line inputs -> the lines the reference prints while it
+                prepares N (main.c:393-527) and, for two of them, the save lines of a short run
+
+usage: python tests/golden/make_golden.py [--only stage1|l0|inputs] [--quick]
 """
 import json, os, random, re, subprocess, sys, tempfile, hashlib
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 REFDIR = os.path.join(ROOT, "oracle", "_ref")
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from xladder import true_stage1_point  # noqa: E402
 
 
 def rand_n(bits):
@@ -135,6 +140,57 @@ def gen_l0():
     json.dump(out, open(os.path.join(HERE, "l0.json"), "w"), indent=0)
 
 
+def gen_inputs():
+    """Cunningham-type inputs (main.c:405-457, 505-527)."""
+    def phi2(m):                               # cyclotomic polynomial value Phi_m(2)
+        def mu(k):
+            r, p = 1, 2
+            while p * p <= k:
+                if k % p == 0:
+                    k //= p
+                    if k % p == 0:
+                        return 0
+                    r = -r
+                p += 1
+            return -r if k > 1 else r
+        num = den = 1
+        for d in range(1, m + 1):
+            if m % d == 0:
+                if mu(m // d) == 1:
+                    num *= 2 ** d - 1
+                elif mu(m // d) == -1:
+                    den *= 2 ** d - 1
+        return num // den
+    redc = phi2(105) * phi2(210)               # | 2^210 - 1, 97 bits: the reference stays with REDC
+    cof251 = (2 ** 251 - 1) // 503 // 54217    # cofactor of M251: the reference folds modulo 2^251 - 1
+    exprs = [str(redc), str(cof251), "2^210-1", "2^300+1", "2^251-1", "2^1009-1", "2^945+1", "2^127-1",
+             "(2^61-1)*(2^89-1)", "2^1155-1", "2^64+13", "2^400-593", "11526466273339081241",
+             "fib(791)/13/677/216416017", "(2^499-1)/20959", "(2^523+1)/3"]
+    exe = os.path.join(REFDIR, "avx-ecm-52")
+    banner, runs = [], []
+    for e in exprs:
+        with tempfile.TemporaryDirectory() as d:
+            p = subprocess.run([exe, e, "8", "100", "1", "100", "1000"], cwd=d, capture_output=True, text=True, timeout=600)
+        keep = [l for l in p.stdout.splitlines() if l.startswith(("gen:", "removing", "commencing", "Mersenne input"))]
+        m = re.search(r"commencing parallel ecm on (\d+)", p.stdout)
+        banner.append({"expr": e, "lines": keep, "N": m.group(1) if m else None,
+                       "special_reduction": "Using special" in p.stdout})
+        print("inputs:", e[:40], len(keep), flush=True)
+    for name, e in (("redc_phi105_phi210", str(redc)), ("special_m251_cofactor", str(cof251))):
+        c = run_ref(52, e, 8, 2000, 2000, 1000)
+        c["name"] = name
+        n = int(c["save_lines"][0].split("N=0x")[1].split(";")[0], 16)
+        ok = []
+        for l in c["save_lines"]:
+            g = lambda key: int(l.split(key + "=0x")[1].split(";")[0], 16)
+            X, Z = true_stage1_point(n, int(l.split("SIGMA=")[1].split(";")[0]), 2000)
+            ok.append((X * g("Z") - g("X") * Z) % n == 0)
+        c["reference_lane_is_the_true_point"] = ok
+        runs.append(c)
+        print("inputs run:", name, ok, flush=True)
+    json.dump({"banner": banner, "runs": runs}, open(os.path.join(HERE, "inputs.json"), "w"), indent=1)
+
+
 if __name__ == "__main__":
     only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else None
     quick = "--quick" in sys.argv
@@ -142,3 +198,5 @@ if __name__ == "__main__":
         gen_l0()
     if only in (None, "stage1"):
         gen_stage1(quick)
+    if only in (None, "inputs"):
+        gen_inputs()

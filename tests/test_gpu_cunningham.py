@@ -1,0 +1,66 @@
+"""Cunningham-type inputs (N | 2^k -/+ 1) on the GPU.
+
+The reference strips algebraic factors and then either keeps REDC (small cofactor) or switches to
+multiplication modulo 2^k -/+ 1 (main.c:405-527).  libgecm always uses REDC modulo N:
+ * REDC case: save_b1.txt of the avx-ecm driver is byte-identical to the reference's, banner lines included;
+ * special-reduction case: the reference's save lines hold residues modulo 2^k -/+ 1; ours are the same
+   residues modulo N on every lane where the reference's value is the true point [k]P (checked against an
+   independent x-only ladder, tests/xladder.py).  On the fixture the reference is wrong on one lane of
+   eight (sigma 1006); there the GPU result is checked against the independent ladder alone."""
+import json
+import os
+import subprocess
+import tempfile
+
+import pytest
+
+from conftest import GOLDEN, ROOT
+from xladder import true_stage1_point
+
+pytestmark = pytest.mark.gpu
+FIX = json.load(open(os.path.join(GOLDEN, "inputs.json")))
+RUNS = {c["name"]: c for c in FIX["runs"]}
+EXE = os.path.join(ROOT, "avx-ecm_amd", "avx-ecm")
+
+
+def _field(line, key):
+    return int(line.split(key + "=0x")[1].split(";")[0], 16)
+
+
+def test_redc_case_driver_output_is_the_references():
+    c = RUNS["redc_phi105_phi210"]
+    banner = next(b for b in FIX["banner"] if b["expr"] == c["N"])
+    with tempfile.TemporaryDirectory() as d:
+        p = subprocess.run([EXE, c["N"], "8", str(c["B1"]), "1", str(c["B2"]), str(c["sigma0"])], cwd=d,
+                           capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stdout + p.stderr
+        save = open(os.path.join(d, "save_b1.txt")).read().splitlines()
+        res = [l for l in open(os.path.join(d, "ecm_results.txt")).read().splitlines() if l.strip()]
+    assert save == c["save_lines"]
+    assert res == c["results_lines"]
+    out = p.stdout.splitlines()
+    pos = [out.index(l) for l in banner["lines"]]          # every banner line, in the reference's order
+    assert pos == sorted(pos)
+    assert "Choosing MAXBITS = %d, NWORDS = %d, NBLOCKS = %d based on input size 97" % (c["maxbits"], c["nwords"], c["nwords"] // 4) in p.stdout
+
+
+def test_special_reduction_case_residues_equal_the_references_modulo_n():
+    import pyecm
+    c = RUNS["special_m251_cofactor"]
+    n = int(c["N"])
+    sig = [int(l.split("SIGMA=")[1].split(";")[0]) for l in c["save_lines"]]
+    good = c["reference_lane_is_the_true_point"]
+    assert sum(good) == 7 and not good[6]
+    for lanes in (1, 2):
+        eng = pyecm.Engine(n, digitbits=52)
+        eng.build_curves(sig)
+        eng.set_lanes_per_curve(lanes)
+        eng.stage1(c["B1"])
+        mine = eng.save_lines()
+        eng.close()
+        for k, (l, r) in enumerate(zip(mine, c["save_lines"])):
+            assert _field(l, "N") == _field(r, "N") == n
+            X, Z = true_stage1_point(n, sig[k], c["B1"])
+            assert (X * _field(l, "Z") - _field(l, "X") * Z) % n == 0
+            if good[k]:
+                assert _field(l, "X") == _field(r, "X") % n and _field(l, "Z") == _field(r, "Z") % n
