@@ -24,9 +24,9 @@ struct Pt {
 };
 
 // P = 2*(point whose sum/diff are s, d).  ecm.c:447-454.
-template <int NL>
+template <int NL, class MOD>
 __device__ __forceinline__ void pt_dup(Pt<NL> &out, const Fe<NL> &s, const Fe<NL> &d, const Fe<NL> &s4,
-                                       const ModK<NL> &m)
+                                       const MOD &m)
 {
     Fe<NL> t1, t2, t3;
     fe_sqr(t1, d, m);        // V = (x-z)^2
@@ -46,9 +46,9 @@ __device__ __forceinline__ void pt_sumdiff(Fe<NL> &s, Fe<NL> &d, const Pt<NL> &p
 }
 
 // First half of pt_add: pp = (U+V)^2, mm = (U-V)^2  (ecm.c:417-422)
-template <int NL>
+template <int NL, class MOD>
 __device__ __forceinline__ void pt_add_uv(Fe<NL> &pp, Fe<NL> &mm, const Fe<NL> &s1, const Fe<NL> &d1,
-                                          const Fe<NL> &s2, const Fe<NL> &d2, const ModK<NL> &m)
+                                          const Fe<NL> &s2, const Fe<NL> &d2, const MOD &m)
 {
     Fe<NL> u, v;
     fe_mul(u, d1, s2, m);   // U
@@ -119,10 +119,10 @@ struct TapePolicy {
 // Register budget (<=256 VGPRs for 2 waves/SIMD): the difference point is only copied after
 // the first half of the addition, and s = (A+2)/4 is re-read from memory for each doubling
 // (doublings are ~10% of the steps) instead of occupying NL registers throughout.
-template <int NL>
+template <int NL, class MOD>
 __device__ __forceinline__ void run_tape(const uint32_t *__restrict__ tape, uint32_t tape_len, Pt<NL> &A,
                                          const uint32_t *__restrict__ S, size_t stride, uint32_t idx,
-                                         const ModK<NL> &m, CStore<NL, TapePolicy<NL>::c_in_lds> &cst)
+                                         const MOD &m, CStore<NL, TapePolicy<NL>::c_in_lds> &cst)
 {
     Pt<NL> B = A;
     cst.put(A);
@@ -298,9 +298,9 @@ __device__ __forceinline__ void pair_diff_sum(Fe<NL> &r, const Fe<NL> &own, bool
 }
 
 // T = P1 + P2 with difference C: fB = pair_diff_sum(P1), fA = pair_sum_diff(P2).  ecm.c:417-440
-template <int NL>
+template <int NL, class MOD>
 __device__ __forceinline__ void pair_add(Fe<NL> &T, const Fe<NL> &fB, const Fe<NL> &fA, const Fe<NL> &c, bool isZ,
-                                         const ModK<NL> &m)
+                                         const MOD &m)
 {
     Fe<NL> w, t, e;
     fe_mul(w, fB, fA, m);              // X lane: U = (x1-z1)(x2+z2)     Z lane: V = (x1+z1)(x2-z2)
@@ -312,9 +312,9 @@ __device__ __forceinline__ void pair_add(Fe<NL> &T, const Fe<NL> &fB, const Fe<N
 }
 
 // D = 2P: fA = pair_sum_diff(P), s4 = (A+2)/4 of this curve.  ecm.c:447-454
-template <int NL>
+template <int NL, class MOD>
 __device__ __forceinline__ void pair_dup(Fe<NL> &D, const Fe<NL> &fA, const Fe<NL> &s4, bool isZ,
-                                         const ModK<NL> &m)
+                                         const MOD &m)
 {
     Fe<NL> q, t, w, p1, p2, r1;
     fe_sqr(q, fA, m);                  // X lane: U = (x+z)^2            Z lane: V = (x-z)^2
@@ -334,10 +334,10 @@ __device__ __forceinline__ void pair_dup(Fe<NL> &D, const Fe<NL> &fA, const Fe<N
 
 // run_tape for the split-coordinate layout: A, B, C are this lane's coordinate of prac()'s three
 // points.  Same tape, same renamings as run_tape above.
-template <int NL>
+template <int NL, class MOD>
 __device__ __forceinline__ void run_tape_pair(const uint32_t *__restrict__ tape, uint32_t tape_len, Fe<NL> &A,
                                               const uint32_t *__restrict__ S, size_t stride, uint32_t cidx,
-                                              bool isZ, const ModK<NL> &m)
+                                              bool isZ, const MOD &m)
 {
     Fe<NL> B = A, C = A;
     auto fetch = [&](uint32_t pc) -> uint32_t {

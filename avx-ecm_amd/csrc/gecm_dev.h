@@ -31,12 +31,17 @@ int gecm_dev_device_name(gecm_dev *d, char *buf, size_t len);
 int gecm_dev_resize(gecm_dev *d, size_t ncurves);
 size_t gecm_dev_stride(gecm_dev *d);
 int gecm_dev_upload(gecm_dev *d, const uint32_t *X, const uint32_t *Z, const uint32_t *S);
+int gecm_dev_upload_xz(gecm_dev *d, const uint32_t *X, const uint32_t *Z);   /* X, Z only; S untouched */
 int gecm_dev_set_tape(gecm_dev *d, const uint8_t *tape, size_t len);
 /* stage 1: asynchronous on the context's stream; HIP events bracket the kernel */
 /* lanes_per_curve: 1 = one curve per lane, 2 = X and Z of a curve on two adjacent lanes (for batches
  * too small to fill the chip), 0 = let the device layer choose from the batch size and CU count */
 int gecm_dev_stage1(gecm_dev *d, int lanes_per_curve);
 int gecm_dev_auto_lanes(gecm_dev *d);
+/* F-form (modulus 2^k - 1, csrc/gecm_field.hpp): number of top limbs the kernel for `nl` limbs reads from
+ * the modulus (all limbs below must be 2^28 - 1), and the switch that makes gecm_dev_stage1 use it. */
+int gecm_dev_fform_generic_limbs(int nl);
+void gecm_dev_set_fform(gecm_dev *d, int on);
 int gecm_dev_last_lanes(gecm_dev *d);
 int gecm_dev_sync(gecm_dev *d);
 float gecm_dev_last_kernel_ms(gecm_dev *d);

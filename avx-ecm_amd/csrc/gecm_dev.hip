@@ -52,6 +52,7 @@ struct gecm_dev {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_ms = 0.f;
     bool timed = false;
+    bool fform = false;   // modulus is 2^k - 1 and stage 1 uses the F-form kernel (gecm_dev_set_fform)
     int cus = 0;          // compute units of the device (4 SIMDs each)
     int last_lanes = 0;   // lanes per curve the last stage-1 launch used
 };
@@ -195,6 +196,15 @@ extern "C" int gecm_dev_upload(gecm_dev *d, const uint32_t *X, const uint32_t *Z
     return 0;
 }
 
+extern "C" int gecm_dev_upload_xz(gecm_dev *d, const uint32_t *X, const uint32_t *Z)
+{
+    HIPCHK(hipSetDevice(d->device));
+    if (upload_soa(d, d->dX, X)) return -1;
+    if (upload_soa(d, d->dZ, Z)) return -1;
+    HIPCHK(hipStreamSynchronize(d->stream));
+    return 0;
+}
+
 extern "C" int gecm_dev_set_tape(gecm_dev *d, const uint8_t *tape, size_t len)
 {
     HIPCHK(hipSetDevice(d->device));
@@ -230,6 +240,18 @@ extern "C" int gecm_dev_auto_lanes(gecm_dev *d)
 
 extern "C" int gecm_dev_last_lanes(gecm_dev *d) { return d->last_lanes; }
 
+extern "C" int gecm_dev_fform_generic_limbs(int nl)
+{
+    switch (nl) {
+#define X(n) case n: return gecm_fform_generic_limbs_##n();
+        GECM_NL_LIST(X)
+#undef X
+    }
+    return -1;
+}
+
+extern "C" void gecm_dev_set_fform(gecm_dev *d, int on) { d->fform = on != 0; }
+
 extern "C" int gecm_dev_stage1(gecm_dev *d, int lanes_per_curve)
 {
     HIPCHK(hipSetDevice(d->device));
@@ -248,7 +270,10 @@ extern "C" int gecm_dev_stage1(gecm_dev *d, int lanes_per_curve)
     switch (d->nl) {
 #define X(n)                                                                                     \
     case n:                                                                                      \
-        if (lanes_per_curve == 2)                                                                \
+        if (d->fform)                                                                            \
+            gecm_launch_stage1_f_##n(d->stream, &mc, d->dTape, (uint32_t)d->tape_len, d->dX,     \
+                                     d->dZ, d->dS, d->stride, lanes_per_curve);                  \
+        else if (lanes_per_curve == 2)                                                           \
             gecm_launch_stage1_pair_##n(d->stream, &mc, d->dTape, (uint32_t)d->tape_len, d->dX,  \
                                         d->dZ, d->dS, d->stride);                                \
         else                                                                                     \

@@ -257,6 +257,128 @@ __device__ __forceinline__ void fe_sqr(Fe<NL> &r, const Fe<NL> &a, const ModK<NL
     r = o;
 }
 
+// ---- moduli of the form 2^k - 1 ("F-form") ---------------------------------------------------
+// For N | 2^k - 1 stage 1 may run modulo Mw = 2^k - 1 instead of N (every residue mod Mw reduces to the
+// right residue mod N; the host reduces once at the end).  Mw in 28-bit limbs is F = 2^28 - 1 in every
+// limb below the one that holds bit k, so in the REDC half of the product scanning
+//     sum_i q_i * n_(c-i)  =  F * (sum of the q_i whose partner limb is an F)  +  (at most G generic terms)
+// with F*T one multiply-add per class sum (FPolicy): the q*N triangle of NL^2 multiply-adds shrinks to
+// about (G+NC)*2NL, and rho = -Mw^-1 mod 2^28 = 1 makes the Montgomery digit a mask.  This is the SAME REDC with the
+// same digits q_i, so every result is the integer the generic fe_mul returns for this modulus; bounds,
+// lazy add/sub and K' are unchanged.  The reference switches such inputs to a folding multiply
+// (vecmulmod52_mersenne, vecarith52.c:284-1031); this is the MI355X counterpart, kept inside REDC.
+// G = number of top limbs read from m.n (they hold the partial limb and possibly zeros): the limb count
+// is the smallest BUILT size with 28*NL >= k+5, so bit k can sit up to (NL - previous built size) limbs
+// below the top.  The host enables the F-form only when limbs 0 .. NL-G-1 of Mw are all F.
+template <int NL>
+struct ModF : ModK<NL> {};
+
+template <int NL>
+struct FPolicy {
+    static constexpr int G = (NL == 26 || NL == 37) ? 4 : (NL == 8 || NL == 15) ? 2 : 3;
+    static constexpr int NF = NL - G;          // limbs 0 .. NF-1 of the modulus are 2^28 - 1
+    // The digits paired with F limbs are summed in NC classes (digit i in class i % NC) of at most 15
+    // digits, so each class sum fits 32 bits and F*T is ONE v_mad_u64_u32 per class (64-bit shift/subtract
+    // sequences cost as much as 4-5 multiply-adds on gfx950: tools/fform_check.py history in DESIGN.md).
+    static constexpr int NC = (NF + 14) / 15;
+};
+
+template <int NL>
+struct FSums {
+    uint32_t t[FPolicy<NL>::NC];
+};
+
+// REDC part of column C.  T = class sums of the digits currently paired with an F limb (excluding q_C).
+template <int C, int NL>
+__device__ __forceinline__ void redc_f_col(uint64_t &acc, FSums<NL> &T, const uint32_t (&q)[NL], const uint32_t (&n)[NL])
+{
+    constexpr int NF = FPolicy<NL>::NF, NC = FPolicy<NL>::NC;
+    if constexpr (C - NF >= 0 && C - NF <= NL - 1) T.t[(C - NF) % NC] -= q[C - NF];   // its partner is now limb NF: generic
+    // class sums that can be non-empty here: digits i in [max(0, C-NF+1), min(C-1, NL-1)] (consecutive);
+    // generic terms: digits i in [max(0, C-NL+1), min(C-NF, NL-1)], partner limb C-i in [NF, NL-1].
+    // All of them go into ONE multiply-add chain (one asm statement: no s_nop padding in between).
+    constexpr int w_lo = (C - NF + 1 > 0) ? C - NF + 1 : 0;
+    constexpr int w_hi = (C - 1 < NL - 1) ? C - 1 : NL - 1;
+    constexpr int wn = (w_hi >= w_lo) ? w_hi - w_lo + 1 : 0;
+    constexpr int cnt = wn < NC ? wn : NC;
+    constexpr int i_lo = (C - NL + 1 > 0) ? C - NL + 1 : 0;
+    constexpr int i_hi = (C - NF < NL - 1) ? C - NF : NL - 1;
+    constexpr int gen = (i_hi >= i_lo) ? i_hi - i_lo + 1 : 0;
+    if constexpr (cnt + gen > 0) {
+        uint32_t x[cnt + gen], y[cnt + gen];
+#pragma unroll
+        for (int j = 0; j < cnt; j++) {
+            x[j] = T.t[(w_lo + j) % NC];
+            y[j] = GECM_LIMB_MASK;                                              // F = 2^28 - 1
+        }
+#pragma unroll
+        for (int j = 0; j < gen; j++) {
+            x[cnt + j] = q[i_lo + j];
+            y[cnt + j] = n[C - i_lo - j];
+        }
+        mad_chain_s<cnt + gen>(acc, x, y);
+    }
+}
+
+template <int NL>
+__device__ __forceinline__ void fe_mul(Fe<NL> &r, const Fe<NL> &a, const Fe<NL> &b, const ModF<NL> &m)
+{
+    uint32_t q[NL];
+    Fe<NL> o;
+    uint64_t acc = 0;
+    FSums<NL> T;
+#pragma unroll
+    for (int j = 0; j < FPolicy<NL>::NC; j++) T.t[j] = 0;
+    static_for<0, NL>([&](auto ic) {
+        constexpr int c = decltype(ic)::value;
+        col_vv<c, 0, c + 1>(acc, a.v, b.v);
+        redc_f_col<c>(acc, T, q, m.n);
+        q[c] = (uint32_t)acc & GECM_LIMB_MASK;                 // rho = 1
+        acc = (acc >> GECM_LIMB_BITS) + q[c];                  // (acc + q*F) >> 28
+        T.t[c % FPolicy<NL>::NC] += q[c];
+    });
+    static_for<NL, 2 * NL>([&](auto ic) {
+        constexpr int c = decltype(ic)::value;
+        col_vv<c, c - NL + 1, NL>(acc, a.v, b.v);
+        redc_f_col<c>(acc, T, q, m.n);
+        o.v[c - NL] = (c == 2 * NL - 1) ? (uint32_t)acc : ((uint32_t)acc & GECM_LIMB_MASK);
+        acc >>= GECM_LIMB_BITS;
+    });
+    r = o;
+}
+
+template <int NL>
+__device__ __forceinline__ void fe_sqr(Fe<NL> &r, const Fe<NL> &a, const ModF<NL> &m)
+{
+    uint32_t q[NL];
+    uint32_t a2[NL];
+    Fe<NL> o;
+#pragma unroll
+    for (int i = 0; i < NL; i++) a2[i] = a.v[i] << 1;
+    uint64_t acc = 0;
+    FSums<NL> T;
+#pragma unroll
+    for (int j = 0; j < FPolicy<NL>::NC; j++) T.t[j] = 0;
+    static_for<0, NL>([&](auto ic) {
+        constexpr int c = decltype(ic)::value;
+        col_vv<c, 0, (c + 1) / 2>(acc, a.v, a2);
+        if constexpr ((c & 1) == 0) col_vv<c, c / 2, c / 2 + 1>(acc, a.v, a.v);
+        redc_f_col<c>(acc, T, q, m.n);
+        q[c] = (uint32_t)acc & GECM_LIMB_MASK;
+        acc = (acc >> GECM_LIMB_BITS) + q[c];
+        T.t[c % FPolicy<NL>::NC] += q[c];
+    });
+    static_for<NL, 2 * NL>([&](auto ic) {
+        constexpr int c = decltype(ic)::value;
+        col_vv<c, c - NL + 1, (c + 1) / 2>(acc, a.v, a2);
+        if constexpr ((c & 1) == 0 && c / 2 < NL) col_vv<c, c / 2, c / 2 + 1>(acc, a.v, a.v);
+        redc_f_col<c>(acc, T, q, m.n);
+        o.v[c - NL] = (c == 2 * NL - 1) ? (uint32_t)acc : ((uint32_t)acc & GECM_LIMB_MASK);
+        acc >>= GECM_LIMB_BITS;
+    });
+    r = o;
+}
+
 // Parallel (carry-save) renormalisation: limbs < 2^30 in, limbs < 2^28 + 4 out, value unchanged.
 template <int NL>
 __device__ __forceinline__ void fe_weak_norm(Fe<NL> &r)
@@ -311,8 +433,8 @@ __device__ __forceinline__ void fe_cond_sub_n(Fe<NL> &r, const ModK<NL> &m)
 
 // x*R -> x canonical: the reference's "vecmulmod(P->X, one)" de-Montgomeryisation
 // (ecm.c:1327-1331) followed by the reduction to [0,N) every reference op performs.
-template <int NL>
-__device__ __forceinline__ void fe_from_mont_canonical(Fe<NL> &r, const Fe<NL> &a, const ModK<NL> &m)
+template <int NL, class MOD>
+__device__ __forceinline__ void fe_from_mont_canonical(Fe<NL> &r, const Fe<NL> &a, const MOD &m)
 {
     Fe<NL> one;
 #pragma unroll
@@ -323,8 +445,8 @@ __device__ __forceinline__ void fe_from_mont_canonical(Fe<NL> &r, const Fe<NL> &
 
 // Canonical residue of a lazy Montgomery-form value, staying in Montgomery form:
 // mont(a, R mod N) = a, < N + K/16... then one conditional subtract.  rmodn must be canonical.
-template <int NL>
-__device__ __forceinline__ void fe_canonical_mont(Fe<NL> &r, const Fe<NL> &a, const Fe<NL> &rmodn, const ModK<NL> &m)
+template <int NL, class MOD>
+__device__ __forceinline__ void fe_canonical_mont(Fe<NL> &r, const Fe<NL> &a, const Fe<NL> &rmodn, const MOD &m)
 {
     fe_mul(r, a, rmodn, m);        // a*(R mod N)/R = a mod N, value < M*N/R + N < 2N
     fe_cond_sub_n(r, m);

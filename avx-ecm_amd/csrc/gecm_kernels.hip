@@ -47,12 +47,57 @@ k_stage1(const uint32_t *__restrict__ tape, uint32_t tape_len, uint32_t *__restr
     fe_store(Z, stride, idx, oz);
 }
 
+// Stage 1 modulo Mw = 2^k - 1 (gecm_field.hpp, "F-form"): the same interpreter, the REDC half of every
+// multiply replaced by the shift-and-subtract form.  Used by the host for N | 2^k - 1.
+template <int NL>
+struct ModArgsF {
+    ModF<NL> m;
+    Fe<NL> one;
+};
+
+template <int NL>
+__global__ void __launch_bounds__(64, 2)
+k_stage1_f(const uint32_t *__restrict__ tape, uint32_t tape_len, uint32_t *__restrict__ X,
+           uint32_t *__restrict__ Z, const uint32_t *__restrict__ S, size_t stride, ModArgsF<NL> a)
+{
+    uint32_t idx = blockIdx.x * 64u + threadIdx.x;
+    Pt<NL> P;
+    fe_load(P.X, X, stride, idx);
+    fe_load(P.Z, Z, stride, idx);
+    constexpr bool CL = TapePolicy<NL>::c_in_lds;
+    __shared__ uint32_t lds_c[CL ? 2 * NL * 64 : 1];
+    CStore<NL, CL> cst;
+    if constexpr (CL) cst.lds = lds_c + threadIdx.x;
+    run_tape<NL>(tape, tape_len, P, S, stride, idx, a.m, cst);
+    Fe<NL> ox, oz;
+    fe_canonical_mont(ox, P.X, a.one, a.m);
+    fe_canonical_mont(oz, P.Z, a.one, a.m);
+    fe_store(X, stride, idx, ox);
+    fe_store(Z, stride, idx, oz);
+}
+
 // Two lanes per curve (gecm_curve.hpp, "split-coordinate"): lane 2j works on X, lane 2j+1 on Z of
 // curve blockIdx.x*32 + j.  Chosen by the device layer for batches that leave SIMDs under-occupied.
 template <int NL>
 __global__ void __launch_bounds__(64, 2)
 k_stage1_pair(const uint32_t *__restrict__ tape, uint32_t tape_len, uint32_t *__restrict__ X,
               uint32_t *__restrict__ Z, const uint32_t *__restrict__ S, size_t stride, ModArgs<NL> a)
+{
+    const uint32_t cidx = blockIdx.x * 32u + (threadIdx.x >> 1);
+    const bool isZ = (threadIdx.x & 1u) != 0;
+    uint32_t *mine = isZ ? Z : X;
+    Fe<NL> P;
+    fe_load(P, mine, stride, cidx);
+    run_tape_pair<NL>(tape, tape_len, P, S, stride, cidx, isZ, a.m);
+    Fe<NL> o;
+    fe_canonical_mont(o, P, a.one, a.m);
+    fe_store(mine, stride, cidx, o);
+}
+
+template <int NL>
+__global__ void __launch_bounds__(64, 2)
+k_stage1_pair_f(const uint32_t *__restrict__ tape, uint32_t tape_len, uint32_t *__restrict__ X,
+                uint32_t *__restrict__ Z, const uint32_t *__restrict__ S, size_t stride, ModArgsF<NL> a)
 {
     const uint32_t cidx = blockIdx.x * 32u + (threadIdx.x >> 1);
     const bool isZ = (threadIdx.x & 1u) != 0;
@@ -213,6 +258,27 @@ extern "C" void CAT(gecm_launch_stage1_, GECM_NL)(void *stream, const gecm_modco
     hipLaunchKernelGGL(k_stage1<GECM_NL>, dim3((unsigned)(stride / 64)), dim3(64), 0, (hipStream_t)stream, tape,
                        tape_len, X, Z, S, stride, make_args<GECM_NL>(mc));
 }
+
+extern "C" void CAT(gecm_launch_stage1_f_, GECM_NL)(void *stream, const gecm_modconst *mc, const uint32_t *tape,
+                                                     uint32_t tape_len, uint32_t *X, uint32_t *Z,
+                                                     const uint32_t *S, size_t stride, int lanes)
+{
+    ModArgsF<GECM_NL> a;
+    for (int i = 0; i < GECM_NL; i++) {
+        a.m.n[i] = mc->n[i];
+        a.m.kp[i] = mc->kp[i];
+        a.one.v[i] = mc->one[i];
+    }
+    a.m.rho = mc->rho;
+    if (lanes == 2)
+        hipLaunchKernelGGL(k_stage1_pair_f<GECM_NL>, dim3((unsigned)(stride / 32)), dim3(64), 0, (hipStream_t)stream,
+                           tape, tape_len, X, Z, S, stride, a);
+    else
+        hipLaunchKernelGGL(k_stage1_f<GECM_NL>, dim3((unsigned)(stride / 64)), dim3(64), 0, (hipStream_t)stream, tape,
+                           tape_len, X, Z, S, stride, a);
+}
+
+extern "C" int CAT(gecm_fform_generic_limbs_, GECM_NL)(void) { return FPolicy<GECM_NL>::G; }
 
 extern "C" void CAT(gecm_launch_stage1_pair_, GECM_NL)(void *stream, const gecm_modconst *mc, const uint32_t *tape,
                                                         uint32_t tape_len, uint32_t *X, uint32_t *Z,

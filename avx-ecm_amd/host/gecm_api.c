@@ -11,6 +11,7 @@
 #include "gecm_plan.h"
 #include "gecm_pair.h"
 #include "mpl.h"
+#include "cunningham.h"
 #include <pthread.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -67,6 +68,13 @@ struct gecm_ctx {
     uint64_t s2_ptadds, s2_numinv, s2_paired, s2_devinv;
     uint32_t s2_amin_last;
     int lanes_per_curve;     /* 0 = auto, 1, 2 (gecm_set_lanes_per_curve) */
+    /* F-form stage 1 for N | 2^k - 1: a second device context working modulo Mw = 2^k - 1
+     * (csrc/gecm_field.hpp); results are brought back modulo N by ff_settle() */
+    gecm_dev *dev_f;
+    int ff_k, ff_nl, ff_on, ff_pending, ff_loaded, last_on_f;
+    uint64_t ff_tape_B1;
+    mpl_t ff_M, ff_r_mod_m;  /* Mw; 2^(28 ff_nl) mod Mw */
+    uint32_t *ff_n28;        /* n, kp, one for dev_f */
 };
 
 static int pick_nl(int nbits)
@@ -77,12 +85,66 @@ static int pick_nl(int nbits)
     return 0;
 }
 
+/* K' for the lazy subtraction (csrc/gecm_field.hpp): K = 2^j * mod in [R/32, R/16), written with every
+ * limb in [2^28-1, 2^29): +2^28 at limb 0, +2^28-1 in the middle, -1 at the top. */
+static int make_kp(uint32_t *kp, const mpl_t *mod, int nl)
+{
+    mpl_t K;
+    uint32_t *kl = (uint32_t *)calloc((size_t)nl, sizeof(uint32_t));
+    if (!kl) return -1;
+    mpl_shl(&K, mod, (unsigned)(LIMB_BITS * nl - 4 - mpl_bits(mod)));
+    mpl_to_limbs32(kl, 1, nl, LIMB_BITS, &K);
+    for (int i = 0; i < nl; i++) {
+        if (i == 0) kp[i] = kl[i] + (1u << LIMB_BITS);
+        else if (i < nl - 1) kp[i] = kl[i] + (1u << LIMB_BITS) - 1;
+        else kp[i] = kl[i] - 1;
+    }
+    free(kl);
+    return 0;
+}
+
 static void pow2_mod(mpl_t *r, unsigned e, const mpl_t *m)
 {
     mpl_t t;
     mpl_set_u64(&t, 1);
     mpl_shl(&t, &t, e);
     mpl_mod(r, &t, m);
+}
+
+/* N | 2^k - 1 (the reference's isMersenne == 1, main.c:410-419): open a second device context modulo
+ * Mw = 2^k - 1 for the F-form stage-1 kernel when that is the cheaper multiply.  Failure to set it up is
+ * not an error: stage 1 then runs modulo N like everything else. */
+static void ff_setup(gecm_ctx *c)
+{
+    cunningham_form f;
+    cunningham_detect(&f, &c->N, c->digitbits);
+    if (f.form != 1 || f.k < 64) return;
+    const int nlf = pick_nl(f.k);
+    if (!nlf) return;
+    const int G = gecm_dev_fform_generic_limbs(nlf);
+    if (G < 0 || f.k < LIMB_BITS * (nlf - G)) return;                 /* limbs below nl-G must all be 2^28-1 */
+    /* multiply-adds per modular multiplication: nl^2 + G*nl against 2 nl^2 + nl */
+    if ((double)(nlf * nlf + G * nlf) * 1.15 > (double)(2 * c->nl * c->nl + c->nl)) return;
+    mpl_t one;
+    mpl_set_u64(&one, 1);
+    mpl_shl(&c->ff_M, &one, (unsigned)f.k);
+    mpl_sub(&c->ff_M, &c->ff_M, &one);
+    pow2_mod(&c->ff_r_mod_m, (unsigned)(LIMB_BITS * nlf), &c->ff_M);
+    c->ff_n28 = (uint32_t *)calloc((size_t)nlf * 3, sizeof(uint32_t));
+    if (!c->ff_n28) return;
+    mpl_to_limbs32(c->ff_n28, 1, nlf, LIMB_BITS, &c->ff_M);
+    mpl_to_limbs32(c->ff_n28 + 2 * nlf, 1, nlf, LIMB_BITS, &c->ff_r_mod_m);
+    if (make_kp(c->ff_n28 + nlf, &c->ff_M, nlf) ||
+        gecm_dev_open(&c->dev_f, c->device, nlf, c->ff_n28, c->ff_n28 + nlf, c->ff_n28 + 2 * nlf, 1u /* -Mw^-1 mod 2^28 */)) {
+        free(c->ff_n28);
+        c->ff_n28 = NULL;
+        c->dev_f = NULL;
+        return;
+    }
+    gecm_dev_set_fform(c->dev_f, 1);
+    c->ff_k = f.k;
+    c->ff_nl = nlf;
+    c->ff_on = 1;
 }
 
 int gecm_create(gecm_ctx **out, int device, const char *n_str, int digitbits)
@@ -137,20 +199,7 @@ int gecm_create(gecm_ctx **out, int device, const char *n_str, int digitbits)
     c->fix28 = c->one28 + nl;
     mpl_to_limbs32(c->n28, 1, nl, LIMB_BITS, &c->N);
     mpl_to_limbs32(c->one28, 1, nl, LIMB_BITS, &c->rint_mod_n);
-    /* K = 2^k N in [R/32, R/16): bits(K) = 28 nl - 4 */
-    mpl_t K;
-    mpl_shl(&K, &c->N, (unsigned)(LIMB_BITS * nl - 4 - c->nbits));
-    uint32_t *kl = (uint32_t *)calloc((size_t)nl, sizeof(uint32_t));
-    if (!kl) { free(c->n28); free(c); return GECM_ERR_NOMEM; }
-    mpl_to_limbs32(kl, 1, nl, LIMB_BITS, &K);
-    /* K' : same value, limbs shifted into [2^28-1, 2^29): +2^28 at limb 0, +2^28-1 in the middle,
-     * -1 at the top (see csrc/gecm_field.hpp) */
-    for (int i = 0; i < nl; i++) {
-        if (i == 0) c->kp28[i] = kl[i] + (1u << LIMB_BITS);
-        else if (i < nl - 1) c->kp28[i] = kl[i] + (1u << LIMB_BITS) - 1;
-        else c->kp28[i] = kl[i] - 1;
-    }
-    free(kl);
+    if (make_kp(c->kp28, &c->N, nl)) { free(c->n28); free(c); return GECM_ERR_NOMEM; }
     /* fix = Rint^2 / Rref mod N = Rint * ref_to_int */
     mpl_mulmod(&t, &c->rint_mod_n, &c->ref_to_int, &c->N);
     mpl_to_limbs32(c->fix28, 1, nl, LIMB_BITS, &t);
@@ -167,6 +216,7 @@ int gecm_create(gecm_ctx **out, int device, const char *n_str, int digitbits)
     mpl_mulmod(&t, &t, &c->rint_mod_n, &c->N);
     mpl_to_limbs32(c->r3_28, 1, nl, LIMB_BITS, &t);
     gecm_dev_set_s2const(c->dev, c->r3_28, (uint32_t)(2 * c->nbits + 2));
+    ff_setup(c);
     *out = c;
     return GECM_OK;
 }
@@ -189,6 +239,8 @@ void gecm_destroy(gecm_ctx *c)
     if (!c) return;
     gecm_dev_close(c->dev);
     gecm_dev_close(c->dev_l0);
+    gecm_dev_close(c->dev_f);
+    free(c->ff_n28);
     gecm_tape_free(&c->tape);
     free_batch(c);
     gecm_s2_plan_free(&c->s2);
@@ -309,6 +361,9 @@ static int alloc_batch(gecm_ctx *c, size_t batch)
     if (!c->sigma || !c->bad || !c->hx || !c->hz || !c->hacc || !c->hfail) { free_batch(c); return GECM_ERR_NOMEM; }
     c->batch = batch;
     if (gecm_dev_resize(c->dev, batch)) { set_err("%s", gecm_dev_error()); return GECM_ERR_DEVICE; }
+    c->ff_pending = 0;
+    c->ff_loaded = 0;
+    if (c->dev_f && gecm_dev_resize(c->dev_f, batch)) { set_err("%s", gecm_dev_error()); return GECM_ERR_DEVICE; }
     return GECM_OK;
 }
 
@@ -355,6 +410,7 @@ typedef struct {
     const uint64_t *sigma;
     size_t batch, lo, hi;
     uint32_t *hX, *hZ, *hS;
+    uint32_t *fX, *fZ, *fS;   /* the same three values for the F-form context (NULL if unused) */
     int anybad, rc;
 } build_job;
 
@@ -413,6 +469,13 @@ static void *build_slice(void *arg)
         mpl_to_limbs32(j->hX + k, batch, nl, LIMB_BITS, &Xm);
         mpl_to_limbs32(j->hZ + k, batch, nl, LIMB_BITS, &c->rint_mod_n);
         mpl_to_limbs32(j->hS + k, batch, nl, LIMB_BITS, &Sm);
+        if (j->fX) {           /* plain residues mod N, lifted to Montgomery form modulo Mw = 2^k - 1 */
+            mpl_mulmod(&Xm, &X, &c->ff_r_mod_m, &c->ff_M);
+            mpl_mulmod(&Sm, &A, &c->ff_r_mod_m, &c->ff_M);
+            mpl_to_limbs32(j->fX + k, batch, c->ff_nl, LIMB_BITS, &Xm);
+            mpl_to_limbs32(j->fZ + k, batch, c->ff_nl, LIMB_BITS, &c->ff_r_mod_m);
+            mpl_to_limbs32(j->fS + k, batch, c->ff_nl, LIMB_BITS, &Sm);
+        }
     }
     free(x3); free(dens); free(pref);
     return NULL;
@@ -441,6 +504,9 @@ int gecm_build_curves(gecm_ctx *c, const uint64_t *sigma, size_t batch)
     size_t words = (size_t)c->nl * batch;
     uint32_t *hX = (uint32_t *)calloc(words * 3, 4);
     if (!hX) return GECM_ERR_NOMEM;
+    const size_t fwords = c->dev_f ? (size_t)c->ff_nl * batch : 0;
+    uint32_t *fX = fwords ? (uint32_t *)calloc(fwords * 3, 4) : NULL;
+    if (fwords && !fX) { free(hX); return GECM_ERR_NOMEM; }
     int nt = host_threads();
     if ((size_t)nt > batch / 256 + 1) nt = (int)(batch / 256 + 1);
     build_job jobs[64];
@@ -450,6 +516,7 @@ int gecm_build_curves(gecm_ctx *c, const uint64_t *sigma, size_t batch)
         jobs[t].lo = batch * (size_t)t / (size_t)nt;
         jobs[t].hi = batch * (size_t)(t + 1) / (size_t)nt;
         jobs[t].hX = hX; jobs[t].hZ = hX + words; jobs[t].hS = hX + 2 * words;
+        jobs[t].fX = fX; jobs[t].fZ = fX ? fX + fwords : NULL; jobs[t].fS = fX ? fX + 2 * fwords : NULL;
     }
     for (int t = 1; t < nt; t++)
         if (pthread_create(&th[t], NULL, build_slice, &jobs[t])) { build_slice(&jobs[t]); th[t] = 0; }
@@ -460,9 +527,14 @@ int gecm_build_curves(gecm_ctx *c, const uint64_t *sigma, size_t batch)
         if (jobs[t].rc) rc = jobs[t].rc;
         anybad |= jobs[t].anybad;
     }
-    if (rc) { free(hX); return rc; }
+    if (rc) { free(hX); free(fX); return rc; }
     rc = gecm_dev_upload(c->dev, hX, hX + words, hX + 2 * words);
+    if (!rc && fX) {
+        rc = gecm_dev_upload(c->dev_f, fX, fX + fwords, fX + 2 * fwords);
+        c->ff_loaded = !rc;
+    }
     free(hX);
+    free(fX);
     if (rc) { set_err("%s", gecm_dev_error()); return GECM_ERR_DEVICE; }
     return anybad ? 1 : GECM_OK;
 }
@@ -486,7 +558,87 @@ int gecm_upload_points(gecm_ctx *c, const void *X, const void *Z, const void *s,
             mpl_to_limbs32(h + (size_t)k * words + i, batch, nl, LIMB_BITS, &v);
         }
     rc = gecm_dev_upload(c->dev, h, h + words, h + 2 * words);
+    if (!rc && c->dev_f) {
+        /* x*Rint mod N -> x -> x*Rf mod Mw */
+        const size_t fwords = (size_t)c->ff_nl * batch;
+        uint32_t *f = (uint32_t *)calloc(fwords * 3, 4);
+        mpl_t rinv;
+        if (f && mpl_invmod(&rinv, &c->rint_mod_n, &c->N)) {
+            for (int k = 0; k < 3; k++)
+                for (size_t i = 0; i < batch; i++) {
+                    mpl_t v;
+                    mpl_from_limbs32(&v, h + (size_t)k * words + i, batch, nl, LIMB_BITS);
+                    mpl_mulmod(&v, &v, &rinv, &c->N);
+                    mpl_mulmod(&v, &v, &c->ff_r_mod_m, &c->ff_M);
+                    mpl_to_limbs32(f + (size_t)k * fwords + i, batch, c->ff_nl, LIMB_BITS, &v);
+                }
+            c->ff_loaded = !gecm_dev_upload(c->dev_f, f, f + fwords, f + 2 * fwords);
+        }
+        free(f);
+    }
     free(h);
+    if (rc) { set_err("%s", gecm_dev_error()); return GECM_ERR_DEVICE; }
+    return GECM_OK;
+}
+
+/* ---- the F-form detour of stage 1 ------------------------------------------------------------
+ * ff_settle: wait for the stage-1 kernel that ran modulo Mw = 2^k - 1, fetch its X, Z (canonical,
+ * de-Montgomeryised), reduce them modulo N, put them back into Montgomery form modulo N and store them
+ * in the main context as if stage 1 had run there.  Everything after stage 1 (save lines, factor scan,
+ * stage 2) then works on residues modulo N as always. */
+typedef struct {
+    gecm_ctx *c;
+    const uint32_t *fx, *fz;
+    uint32_t *hX, *hZ;
+    size_t lo, hi;
+} settle_job;
+
+static void *settle_slice(void *arg)
+{
+    settle_job *j = (settle_job *)arg;
+    gecm_ctx *c = j->c;
+    const size_t batch = c->batch;
+    for (size_t i = j->lo; i < j->hi; i++) {
+        mpl_t v;
+        mpl_from_limbs32(&v, j->fx + i, batch, c->ff_nl, LIMB_BITS);
+        mpl_mod(&v, &v, &c->N);
+        mpl_mulmod(&v, &v, &c->rint_mod_n, &c->N);
+        mpl_to_limbs32(j->hX + i, batch, c->nl, LIMB_BITS, &v);
+        mpl_from_limbs32(&v, j->fz + i, batch, c->ff_nl, LIMB_BITS);
+        mpl_mod(&v, &v, &c->N);
+        mpl_mulmod(&v, &v, &c->rint_mod_n, &c->N);
+        mpl_to_limbs32(j->hZ + i, batch, c->nl, LIMB_BITS, &v);
+    }
+    return NULL;
+}
+
+static int ff_settle(gecm_ctx *c)
+{
+    if (!c->ff_pending) return GECM_OK;
+    c->ff_pending = 0;
+    if (gecm_dev_sync(c->dev_f)) { set_err("%s", gecm_dev_error()); return GECM_ERR_DEVICE; }
+    c->last_ms = gecm_dev_last_kernel_ms(c->dev_f);
+    const size_t batch = c->batch, fwords = (size_t)c->ff_nl * batch, words = (size_t)c->nl * batch;
+    uint32_t *f = (uint32_t *)calloc(2 * fwords + 2 * words, 4);
+    if (!f) return GECM_ERR_NOMEM;
+    if (gecm_dev_download_plain(c->dev_f, f, f + fwords)) { free(f); set_err("%s", gecm_dev_error()); return GECM_ERR_DEVICE; }
+    int nt = host_threads();
+    if ((size_t)nt > batch / 256 + 1) nt = (int)(batch / 256 + 1);
+    settle_job jobs[64];
+    pthread_t th[64];
+    for (int t = 0; t < nt; t++) {
+        jobs[t].c = c; jobs[t].fx = f; jobs[t].fz = f + fwords;
+        jobs[t].hX = f + 2 * fwords; jobs[t].hZ = f + 2 * fwords + words;
+        jobs[t].lo = batch * (size_t)t / (size_t)nt;
+        jobs[t].hi = batch * (size_t)(t + 1) / (size_t)nt;
+    }
+    for (int t = 1; t < nt; t++)
+        if (pthread_create(&th[t], NULL, settle_slice, &jobs[t])) { settle_slice(&jobs[t]); th[t] = 0; }
+    settle_slice(&jobs[0]);
+    for (int t = 1; t < nt; t++)
+        if (th[t]) pthread_join(th[t], NULL);
+    int rc = gecm_dev_upload_xz(c->dev, f + 2 * fwords, f + 2 * fwords + words);
+    free(f);
     if (rc) { set_err("%s", gecm_dev_error()); return GECM_ERR_DEVICE; }
     return GECM_OK;
 }
@@ -494,6 +646,7 @@ int gecm_upload_points(gecm_ctx *c, const void *X, const void *Z, const void *s,
 /* ---- phase 1 -------------------------------------------------------------------------------- */
 int gecm_stage1(gecm_ctx *c, uint64_t B1)
 {
+    if (c && c->ff_pending) { int rcs = ff_settle(c); if (rcs) return rcs; }
     if (!c || c->batch == 0) { set_err("gecm_stage1: no curves uploaded"); return GECM_ERR_STATE; }
     if (B1 < 2 || B1 > 100000000ull) { set_err("gecm_stage1: B1 must be in [2, 1e8]"); return GECM_ERR_ARG; }
     if (c->tape_B1 != B1 || !c->tape.ops) {
@@ -512,8 +665,36 @@ int gecm_stage1(gecm_ctx *c, uint64_t B1)
     c->have_acc = 0;
     c->s2_ready = 0;
     c->scan_valid[0] = c->scan_valid[1] = 0;
+    if (c->dev_f && c->ff_on && c->ff_loaded) {
+        /* N | 2^k - 1: run the chain modulo 2^k - 1 with the F-form multiply; ff_settle brings X, Z back */
+        if (c->ff_tape_B1 != B1) {
+            if (gecm_dev_set_tape(c->dev_f, c->tape.ops, c->tape.len)) { set_err("%s", gecm_dev_error()); return GECM_ERR_DEVICE; }
+            c->ff_tape_B1 = B1;
+        }
+        if (gecm_dev_stage1(c->dev_f, c->lanes_per_curve)) { set_err("%s", gecm_dev_error()); return GECM_ERR_DEVICE; }
+        c->ff_pending = 1;
+        c->last_on_f = 1;
+        return GECM_OK;
+    }
+    c->last_on_f = 0;
+    c->ff_loaded = 0;       /* the F-form copy of the points no longer matches */
     if (gecm_dev_stage1(c->dev, c->lanes_per_curve)) { set_err("%s", gecm_dev_error()); return GECM_ERR_DEVICE; }
     return GECM_OK;
+}
+
+int gecm_set_special_form(gecm_ctx *c, int on)
+{
+    if (!c) return GECM_ERR_ARG;
+    c->ff_on = on != 0;
+    return GECM_OK;
+}
+
+int gecm_get_special_form(const gecm_ctx *c, int *k, int *limbs)
+{
+    if (!c) return GECM_ERR_ARG;
+    if (k) *k = c->dev_f ? c->ff_k : 0;
+    if (limbs) *limbs = c->dev_f ? c->ff_nl : 0;
+    return c->dev_f && c->ff_on ? 1 : 0;
 }
 
 int gecm_set_lanes_per_curve(gecm_ctx *c, int lanes)
@@ -523,11 +704,16 @@ int gecm_set_lanes_per_curve(gecm_ctx *c, int lanes)
     return GECM_OK;
 }
 
-int gecm_get_lanes_per_curve(const gecm_ctx *c) { return c ? gecm_dev_last_lanes(c->dev) : GECM_ERR_ARG; }
+int gecm_get_lanes_per_curve(const gecm_ctx *c)
+{
+    if (!c) return GECM_ERR_ARG;
+    return gecm_dev_last_lanes(c->last_on_f ? c->dev_f : c->dev);
+}
 
 int gecm_sync(gecm_ctx *c)
 {
     if (!c) return GECM_ERR_ARG;
+    if (c->ff_pending) return ff_settle(c);
     if (gecm_dev_sync(c->dev)) { set_err("%s", gecm_dev_error()); return GECM_ERR_DEVICE; }
     c->last_ms = gecm_dev_last_kernel_ms(c->dev);
     return GECM_OK;
@@ -547,6 +733,7 @@ int gecm_get_stage1_stats(const gecm_ctx *c, gecm_stage1_stats *st)
 
 int gecm_download_points(gecm_ctx *c, void *X, void *Z)
 {
+    if (c && c->ff_pending) { int rcs = ff_settle(c); if (rcs) return rcs; }
     if (!c || !X || !Z || c->batch == 0) return GECM_ERR_ARG;
     size_t batch = c->batch, words = (size_t)c->nl * batch;
     uint32_t *h = (uint32_t *)malloc(words * 2 * 4);
@@ -566,6 +753,7 @@ int gecm_download_points(gecm_ctx *c, void *X, void *Z)
 
 static int fetch_plain(gecm_ctx *c)
 {
+    if (c->ff_pending) { int rcs = ff_settle(c); if (rcs) return rcs; }
     if (c->have_plain) return GECM_OK;
     if (c->batch == 0) { set_err("no batch"); return GECM_ERR_STATE; }
     if (gecm_dev_download_plain(c->dev, c->hx, c->hz)) { set_err("%s", gecm_dev_error()); return GECM_ERR_DEVICE; }
@@ -650,6 +838,7 @@ static uint64_t ladder_adds(uint64_t c)
 
 int gecm_stage2_init(gecm_ctx *c, uint32_t D, uint32_t U)
 {
+    if (c && c->ff_pending) { int rcs = ff_settle(c); if (rcs) return rcs; }
     if (!c || c->batch == 0 || c->B1 == 0) { set_err("gecm_stage2_init: run stage 1 first"); return GECM_ERR_STATE; }
     if (!D) D = gecm_s2_default_D(c->B1);
     if (!U) U = GECM_S2_DEFAULT_U;
@@ -839,6 +1028,7 @@ int gecm_stage2_factor(gecm_ctx *c, size_t k, char *dec, size_t declen, int *is_
 /* ---- device factor scan ------------------------------------------------------------------- */
 int gecm_scan_factors(gecm_ctx *c, int stage, size_t *first)
 {
+    if (c && c->ff_pending) { int rcs = ff_settle(c); if (rcs) return rcs; }
     if (!c || c->batch == 0 || (stage != 1 && stage != 2)) { set_err("gecm_scan_factors: bad argument"); return GECM_ERR_ARG; }
     if (stage == 2 && !c->s2_ready) { set_err("gecm_scan_factors: no stage-2 state"); return GECM_ERR_STATE; }
     uint32_t **f = &c->flags[stage - 1], **hg = &c->hg[stage - 1];

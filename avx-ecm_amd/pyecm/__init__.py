@@ -40,7 +40,7 @@ EXPORTS = ["gecm_last_error", "gecm_device_count", "gecm_version", "gecm_create"
            "gecm_upload_points", "gecm_stage1", "gecm_sync", "gecm_last_kernel_ms",
            "gecm_get_stage1_stats", "gecm_download_points", "gecm_download_points_plain",
            "gecm_format_save_line", "gecm_stage1_factor", "gecm_set_lanes_per_curve",
-           "gecm_get_lanes_per_curve"]
+           "gecm_get_lanes_per_curve", "gecm_set_special_form", "gecm_get_special_form"]
 
 _sig("gecm_last_error", c_char_p)
 _sig("gecm_device_count", c_int)
@@ -61,6 +61,8 @@ _sig("gecm_stage1", c_int, c_void_p, c_u64)
 _sig("gecm_sync", c_int, c_void_p)
 _sig("gecm_set_lanes_per_curve", c_int, c_void_p, c_int)
 _sig("gecm_get_lanes_per_curve", c_int, c_void_p)
+_sig("gecm_set_special_form", c_int, c_void_p, c_int)
+_sig("gecm_get_special_form", c_int, c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int))
 _sig("gecm_last_kernel_ms", c_double, c_void_p)
 _sig("gecm_get_stage1_stats", c_int, c_void_p, ctypes.POINTER(Stage1Stats))
 _sig("gecm_download_points", c_int, c_void_p, c_void_p, c_void_p)
@@ -210,6 +212,16 @@ class Engine:
     def set_lanes_per_curve(self, lanes):
         """0 = chosen per launch from the batch size, 1 = curve per lane, 2 = X and Z on adjacent lanes"""
         _chk(lib.gecm_set_lanes_per_curve(self._h, lanes), "gecm_set_lanes_per_curve")
+
+    def set_special_form(self, on):
+        """use (default) or not the 2^k - 1 multiply for N | 2^k - 1; applies from the next build/upload"""
+        _chk(lib.gecm_set_special_form(self._h, 1 if on else 0), "gecm_set_special_form")
+
+    def special_form(self):
+        """(in use, k, limbs)"""
+        k, l = c_int(0), c_int(0)
+        r = _chk(lib.gecm_get_special_form(self._h, ctypes.byref(k), ctypes.byref(l)), "gecm_get_special_form")
+        return bool(r), k.value, l.value
 
     def lanes_per_curve(self):
         """what the last stage-1 launch used"""

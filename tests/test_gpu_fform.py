@@ -1,0 +1,66 @@
+"""Stage 1 modulo 2^k - 1 for N | 2^k - 1 (the "F-form" multiply, csrc/gecm_field.hpp; the reference's
+isMersenne == 1 inputs).  The kernel runs the same REDC with the same digits modulo Mw = 2^k - 1 and the
+host reduces modulo N, so the save lines must be byte-identical to the generic path's for every curve."""
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _lines(n, sig, b1, special):
+    import pyecm
+    eng = pyecm.Engine(n, digitbits=52)
+    avail = eng.special_form()
+    eng.set_special_form(special)
+    eng.build_curves(sig)
+    eng.stage1(b1)
+    used = eng.special_form()[0] and special
+    lines = eng.save_lines()
+    facs = [eng.stage1_factor(k) for k in range(len(sig))]
+    eng.close()
+    return lines, facs, avail, used
+
+
+@pytest.mark.parametrize("k,cof", [(170, 1), (251, 503 * 54217), (401, 1), (521, 1), (607, 1), (701, 1), (929, 1), (1009, 1)])
+def test_special_form_stage1_equals_generic_path(k, cof):
+    n = ((1 << k) - 1) // cof
+    sig = list(range(2000, 2070))
+    a, fa, avail, used = _lines(n, sig, 3000, True)
+    assert avail[0] and avail[1] == k and used, (avail, used)
+    b, fb, _, used_b = _lines(n, sig, 3000, False)
+    assert not used_b
+    assert a == b and fa == fb
+
+
+def test_special_form_is_not_used_when_it_cannot_be():
+    import pyecm
+    # k = 150: bit k sits lower than the kernel's generic top limbs reach -> plain REDC
+    eng = pyecm.Engine((1 << 150) - 1)
+    assert eng.special_form() == (False, 0, 0)
+    eng.close()
+    # a generic N has no such form
+    eng = pyecm.Engine((1 << 300) + 157)
+    assert eng.special_form() == (False, 0, 0)
+    eng.close()
+    # a small cofactor of a large 2^k - 1: REDC on the cofactor is the cheaper multiply (as main.c:505-516 decides too)
+    eng = pyecm.Engine(((1 << 89) - 1) * ((1 << 107) - 1) * 13367)      # divides 2^9523-1: k beyond the detection loop
+    assert eng.special_form()[0] is False
+    eng.close()
+
+
+def test_special_form_survives_a_second_stage1_and_stage2():
+    """stage 1 twice on the same batch continues from [k]P in both paths; stage 2 then runs modulo N"""
+    import pyecm
+    n = (1 << 401) - 1
+    sig = list(range(3000, 3064))
+    out = {}
+    for special in (True, False):
+        eng = pyecm.Engine(n)
+        eng.set_special_form(special)
+        eng.build_curves(sig)
+        eng.stage1(500)
+        eng.stage1(500)
+        lines = eng.save_lines()
+        eng.stage2(20000)
+        out[special] = (lines, eng.download_acc())
+        eng.close()
+    assert out[True] == out[False]
