@@ -144,9 +144,6 @@ int main(int argc, char **argv)
     numcurves = (numcurves + 7) / 8 * 8;
 
     fputs(prep_log, stdout);          /* "gen: ...", "removing algebraic ...", "commencing parallel ecm on ..." */
-    if (inf.ref_special_reduction)
-        printf("Input divides 2^%d %c %d: no special reduction on the GPU, REDC on the %d-bit cofactor "
-               "(residues = the reference's modulo N)\n", inf.k, inf.form > 0 ? '-' : '+', inf.form, inf.nbits);
     job_t jobs[MAX_GPUS];
     memset(jobs, 0, sizeof jobs);
     for (int g = 0; g < gpus; g++) {
@@ -162,6 +159,16 @@ int main(int argc, char **argv)
            cfg.digitbits, cfg.dev_limbs, gpus, devname);
     printf("Choosing MAXBITS = %d, NWORDS = %d, NBLOCKS = %d based on input size %d\n", cfg.maxbits, cfg.nwords,
            cfg.nwords / 4, cfg.nbits);
+    if (inf.ref_special_reduction) {
+        /* main.c:644-670 prints "Using special Mersenne mod for factor of: 2^k-1" here */
+        int fk = 0, fl = 0;
+        if (gecm_get_special_form(jobs[0].ctx, &fk, &fl) == 1)
+            printf("Using REDC modulo 2^%d-1 (%d limbs, reduction by class sums) for stage 1 of this factor of 2^%d-1; "
+                   "residues are reduced modulo N\n", fk, fl, fk);
+        else
+            printf("Input divides 2^%d %c %d: running REDC on the %d-bit cofactor (residues = the reference's modulo N)\n",
+                   inf.k, inf.form > 0 ? '-' : '+', inf.form, inf.nbits);
+    }
     if (sigma0) printf("starting with sigma = %lu\n", (unsigned long)sigma0);     /* main.c:558 */
     size_t per_pass = (size_t)FULL_BATCH * (size_t)gpus;
     printf("Input has %d bits, using %d GPU(s) (%zu curves/pass)\n", cfg.nbits, gpus,
