@@ -52,7 +52,7 @@ struct gecm_dev {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_ms = 0.f;
     bool timed = false;
-    bool fform = false;   // modulus is 2^k - 1 and stage 1 uses the F-form kernel (gecm_dev_set_fform)
+    int fform = 0;        // +1 / -1: modulus is 2^k - 1 / 2^k + 1 and stage 1 uses the special multiply (gecm_dev_set_fform)
     int cus = 0;          // compute units of the device (4 SIMDs each)
     int last_lanes = 0;   // lanes per curve the last stage-1 launch used
 };
@@ -250,7 +250,7 @@ extern "C" int gecm_dev_fform_generic_limbs(int nl)
     return -1;
 }
 
-extern "C" void gecm_dev_set_fform(gecm_dev *d, int on) { d->fform = on != 0; }
+extern "C" void gecm_dev_set_fform(gecm_dev *d, int form) { d->fform = form > 0 ? 1 : form < 0 ? -1 : 0; }
 
 extern "C" int gecm_dev_stage1(gecm_dev *d, int lanes_per_curve)
 {
@@ -272,7 +272,7 @@ extern "C" int gecm_dev_stage1(gecm_dev *d, int lanes_per_curve)
     case n:                                                                                      \
         if (d->fform)                                                                            \
             gecm_launch_stage1_f_##n(d->stream, &mc, d->dTape, (uint32_t)d->tape_len, d->dX,     \
-                                     d->dZ, d->dS, d->stride, lanes_per_curve);                  \
+                                     d->dZ, d->dS, d->stride, lanes_per_curve, d->fform);       \
         else if (lanes_per_curve == 2)                                                           \
             gecm_launch_stage1_pair_##n(d->stream, &mc, d->dTape, (uint32_t)d->tape_len, d->dX,  \
                                         d->dZ, d->dS, d->stride);                                \

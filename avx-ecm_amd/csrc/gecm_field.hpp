@@ -379,6 +379,75 @@ __device__ __forceinline__ void fe_sqr(Fe<NL> &r, const Fe<NL> &a, const ModF<NL
     r = o;
 }
 
+// ---- moduli of the form 2^k + 1 ("P-form") ---------------------------------------------------
+// Mw = 2^k + 1 in 28-bit limbs is 1, 0, ..., 0 below the limb that holds bit k, and rho = -Mw^-1 mod 2^28
+// = 2^28 - 1.  The REDC half of a column is then: the digit q_c = (-acc) mod 2^28, its product with limb 0
+// (an addition), and the generic terms with the top G limbs (only one of which is non-zero).  Same REDC,
+// same digits, same integers as the generic multiply for this modulus.  The reference's counterpart is
+// the isMersenne == -1 branch of vecmulmod52_mersenne (vecarith52.c:973-1027).
+template <int NL>
+struct ModP : ModK<NL> {};
+
+template <int C, int NL>
+__device__ __forceinline__ void redc_p_col(uint64_t &acc, const uint32_t (&q)[NL], const uint32_t (&n)[NL])
+{
+    constexpr int NF = FPolicy<NL>::NF;
+    constexpr int i_lo = (C - NL + 1 > 0) ? C - NL + 1 : 0;
+    constexpr int i_hi = (C - NF < NL - 1) ? C - NF : NL - 1;              // partner limb index C-i in [NF, NL-1]
+    if constexpr (i_hi >= i_lo) col_vs<C, i_lo, i_hi + 1>(acc, q, n);
+}
+
+template <int NL>
+__device__ __forceinline__ void fe_mul(Fe<NL> &r, const Fe<NL> &a, const Fe<NL> &b, const ModP<NL> &m)
+{
+    uint32_t q[NL];
+    Fe<NL> o;
+    uint64_t acc = 0;
+    static_for<0, NL>([&](auto ic) {
+        constexpr int c = decltype(ic)::value;
+        col_vv<c, 0, c + 1>(acc, a.v, b.v);
+        redc_p_col<c>(acc, q, m.n);
+        q[c] = (0u - (uint32_t)acc) & GECM_LIMB_MASK;          // rho = -1
+        acc = (acc + q[c]) >> GECM_LIMB_BITS;                  // limb 0 of the modulus is 1
+    });
+    static_for<NL, 2 * NL>([&](auto ic) {
+        constexpr int c = decltype(ic)::value;
+        col_vv<c, c - NL + 1, NL>(acc, a.v, b.v);
+        redc_p_col<c>(acc, q, m.n);
+        o.v[c - NL] = (c == 2 * NL - 1) ? (uint32_t)acc : ((uint32_t)acc & GECM_LIMB_MASK);
+        acc >>= GECM_LIMB_BITS;
+    });
+    r = o;
+}
+
+template <int NL>
+__device__ __forceinline__ void fe_sqr(Fe<NL> &r, const Fe<NL> &a, const ModP<NL> &m)
+{
+    uint32_t q[NL];
+    uint32_t a2[NL];
+    Fe<NL> o;
+#pragma unroll
+    for (int i = 0; i < NL; i++) a2[i] = a.v[i] << 1;
+    uint64_t acc = 0;
+    static_for<0, NL>([&](auto ic) {
+        constexpr int c = decltype(ic)::value;
+        col_vv<c, 0, (c + 1) / 2>(acc, a.v, a2);
+        if constexpr ((c & 1) == 0) col_vv<c, c / 2, c / 2 + 1>(acc, a.v, a.v);
+        redc_p_col<c>(acc, q, m.n);
+        q[c] = (0u - (uint32_t)acc) & GECM_LIMB_MASK;
+        acc = (acc + q[c]) >> GECM_LIMB_BITS;
+    });
+    static_for<NL, 2 * NL>([&](auto ic) {
+        constexpr int c = decltype(ic)::value;
+        col_vv<c, c - NL + 1, (c + 1) / 2>(acc, a.v, a2);
+        if constexpr ((c & 1) == 0 && c / 2 < NL) col_vv<c, c / 2, c / 2 + 1>(acc, a.v, a.v);
+        redc_p_col<c>(acc, q, m.n);
+        o.v[c - NL] = (c == 2 * NL - 1) ? (uint32_t)acc : ((uint32_t)acc & GECM_LIMB_MASK);
+        acc >>= GECM_LIMB_BITS;
+    });
+    r = o;
+}
+
 // Parallel (carry-save) renormalisation: limbs < 2^30 in, limbs < 2^28 + 4 out, value unchanged.
 template <int NL>
 __device__ __forceinline__ void fe_weak_norm(Fe<NL> &r)

@@ -49,16 +49,17 @@ k_stage1(const uint32_t *__restrict__ tape, uint32_t tape_len, uint32_t *__restr
 
 // Stage 1 modulo Mw = 2^k - 1 (gecm_field.hpp, "F-form"): the same interpreter, the REDC half of every
 // multiply replaced by the shift-and-subtract form.  Used by the host for N | 2^k - 1.
-template <int NL>
-struct ModArgsF {
-    ModF<NL> m;
+template <int NL, class MOD>
+struct ModArgsS {
+    MOD m;
     Fe<NL> one;
 };
 
-template <int NL>
+// MOD = ModF<NL> (2^k - 1) or ModP<NL> (2^k + 1)
+template <int NL, class MOD>
 __global__ void __launch_bounds__(64, 2)
 k_stage1_f(const uint32_t *__restrict__ tape, uint32_t tape_len, uint32_t *__restrict__ X,
-           uint32_t *__restrict__ Z, const uint32_t *__restrict__ S, size_t stride, ModArgsF<NL> a)
+           uint32_t *__restrict__ Z, const uint32_t *__restrict__ S, size_t stride, ModArgsS<NL, MOD> a)
 {
     uint32_t idx = blockIdx.x * 64u + threadIdx.x;
     Pt<NL> P;
@@ -94,10 +95,10 @@ k_stage1_pair(const uint32_t *__restrict__ tape, uint32_t tape_len, uint32_t *__
     fe_store(mine, stride, cidx, o);
 }
 
-template <int NL>
+template <int NL, class MOD>
 __global__ void __launch_bounds__(64, 2)
 k_stage1_pair_f(const uint32_t *__restrict__ tape, uint32_t tape_len, uint32_t *__restrict__ X,
-                uint32_t *__restrict__ Z, const uint32_t *__restrict__ S, size_t stride, ModArgsF<NL> a)
+                uint32_t *__restrict__ Z, const uint32_t *__restrict__ S, size_t stride, ModArgsS<NL, MOD> a)
 {
     const uint32_t cidx = blockIdx.x * 32u + (threadIdx.x >> 1);
     const bool isZ = (threadIdx.x & 1u) != 0;
@@ -259,11 +260,11 @@ extern "C" void CAT(gecm_launch_stage1_, GECM_NL)(void *stream, const gecm_modco
                        tape_len, X, Z, S, stride, make_args<GECM_NL>(mc));
 }
 
-extern "C" void CAT(gecm_launch_stage1_f_, GECM_NL)(void *stream, const gecm_modconst *mc, const uint32_t *tape,
-                                                     uint32_t tape_len, uint32_t *X, uint32_t *Z,
-                                                     const uint32_t *S, size_t stride, int lanes)
+template <class MOD>
+static void launch_stage1_special(void *stream, const gecm_modconst *mc, const uint32_t *tape, uint32_t tape_len,
+                                  uint32_t *X, uint32_t *Z, const uint32_t *S, size_t stride, int lanes)
 {
-    ModArgsF<GECM_NL> a;
+    ModArgsS<GECM_NL, MOD> a;
     for (int i = 0; i < GECM_NL; i++) {
         a.m.n[i] = mc->n[i];
         a.m.kp[i] = mc->kp[i];
@@ -271,11 +272,20 @@ extern "C" void CAT(gecm_launch_stage1_f_, GECM_NL)(void *stream, const gecm_mod
     }
     a.m.rho = mc->rho;
     if (lanes == 2)
-        hipLaunchKernelGGL(k_stage1_pair_f<GECM_NL>, dim3((unsigned)(stride / 32)), dim3(64), 0, (hipStream_t)stream,
-                           tape, tape_len, X, Z, S, stride, a);
+        hipLaunchKernelGGL((k_stage1_pair_f<GECM_NL, MOD>), dim3((unsigned)(stride / 32)), dim3(64), 0,
+                           (hipStream_t)stream, tape, tape_len, X, Z, S, stride, a);
     else
-        hipLaunchKernelGGL(k_stage1_f<GECM_NL>, dim3((unsigned)(stride / 64)), dim3(64), 0, (hipStream_t)stream, tape,
-                           tape_len, X, Z, S, stride, a);
+        hipLaunchKernelGGL((k_stage1_f<GECM_NL, MOD>), dim3((unsigned)(stride / 64)), dim3(64), 0, (hipStream_t)stream,
+                           tape, tape_len, X, Z, S, stride, a);
+}
+
+/* form: +1 = modulus 2^k - 1 (F-form), -1 = modulus 2^k + 1 (P-form) */
+extern "C" void CAT(gecm_launch_stage1_f_, GECM_NL)(void *stream, const gecm_modconst *mc, const uint32_t *tape,
+                                                     uint32_t tape_len, uint32_t *X, uint32_t *Z,
+                                                     const uint32_t *S, size_t stride, int lanes, int form)
+{
+    if (form > 0) launch_stage1_special<ModF<GECM_NL>>(stream, mc, tape, tape_len, X, Z, S, stride, lanes);
+    else launch_stage1_special<ModP<GECM_NL>>(stream, mc, tape, tape_len, X, Z, S, stride, lanes);
 }
 
 extern "C" int CAT(gecm_fform_generic_limbs_, GECM_NL)(void) { return FPolicy<GECM_NL>::G; }

@@ -163,8 +163,8 @@ int main(int argc, char **argv)
         /* main.c:644-670 prints "Using special Mersenne mod for factor of: 2^k-1" here */
         int fk = 0, fl = 0;
         if (gecm_get_special_form(jobs[0].ctx, &fk, &fl) == 1)
-            printf("Using REDC modulo 2^%d-1 (%d limbs, reduction by class sums) for stage 1 of this factor of 2^%d-1; "
-                   "residues are reduced modulo N\n", fk, fl, fk);
+            printf("Using REDC modulo 2^%d%c1 (%d limbs, special reduction) for stage 1 of this factor of 2^%d%c1; "
+                   "residues are reduced modulo N\n", abs(fk), fk > 0 ? '-' : '+', fl, abs(fk), fk > 0 ? '-' : '+');
         else
             printf("Input divides 2^%d %c %d: running REDC on the %d-bit cofactor (residues = the reference's modulo N)\n",
                    inf.k, inf.form > 0 ? '-' : '+', inf.form, inf.nbits);

@@ -125,13 +125,14 @@ int gecm_sync(gecm_ctx *ctx);
  * 0 (default) = chosen per launch: 1 when the batch's last round of 128 x 4 x CUs curves is more than
  * three quarters full and N is at most 639 bits, else 2.  Results are identical.
  * gecm_get_lanes_per_curve returns what the last gecm_stage1 launch used (0 before the first). */
-/* N | 2^k - 1 (Mersenne cofactors; the reference's isMersenne == 1, main.c:410-419, for which it switches to
- * vecmulmod52_mersenne): stage 1 runs modulo 2^k - 1 with a multiply whose reduction half is shifts and
- * subtractions instead of multiplications, and X, Z are reduced modulo N when they come back.  Chosen at
+/* N | 2^k - 1 or N | 2^k + 1 (Cunningham cofactors; the reference's isMersenne == +1 / -1, main.c:410-430, for
+ * which it switches to vecmulmod52_mersenne): stage 1 runs modulo 2^k -/+ 1 with a multiply whose reduction
+ * half needs almost no multiplications, and X, Z are reduced modulo N when they come back.  Chosen at
  * gecm_create when it is the cheaper multiply; outputs are the same residues modulo N either way.
  * gecm_set_special_form(ctx, 0) keeps everything on the generic REDC path (takes effect at the next
  * gecm_build_curves / gecm_upload_points).  gecm_get_special_form returns 1 if the special multiply is in
- * use and stores k and the limb count of 2^k - 1 (0, 0 if N has no such form or it would not pay). */
+ * use and stores +k for 2^k - 1, -k for 2^k + 1, and the limb count of that modulus (0, 0 if N has no such
+ * form or it would not pay). */
 int gecm_set_special_form(gecm_ctx *ctx, int on);
 int gecm_get_special_form(const gecm_ctx *ctx, int *k, int *limbs);
 int gecm_set_lanes_per_curve(gecm_ctx *ctx, int lanes);

@@ -64,3 +64,21 @@ def test_special_reduction_case_residues_equal_the_references_modulo_n():
             assert (X * _field(l, "Z") - _field(l, "X") * Z) % n == 0
             if good[k]:
                 assert _field(l, "X") == _field(r, "X") % n and _field(l, "Z") == _field(r, "Z") % n
+
+
+def test_driver_on_a_mersenne_cofactor_names_the_path_and_writes_residues_modulo_n():
+    c = RUNS["special_m251_cofactor"]
+    n = int(c["N"])
+    good = c["reference_lane_is_the_true_point"]
+    with tempfile.TemporaryDirectory() as d:
+        p = subprocess.run([EXE, c["N"], "8", str(c["B1"]), "1", str(c["B2"]), str(c["sigma0"])], cwd=d,
+                           capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stdout + p.stderr
+        save = open(os.path.join(d, "save_b1.txt")).read().splitlines()
+    assert "removing algebraic C1 factor 0" in p.stdout                       # what the reference prints here
+    assert "Using REDC modulo 2^251-1 (10 limbs, special reduction) for stage 1" in p.stdout
+    assert len(save) == 8
+    for k, (l, r) in enumerate(zip(save, c["save_lines"])):
+        assert _field(l, "N") == n and _field(l, "X") < n and _field(l, "Z") < n
+        if good[k]:
+            assert _field(l, "X") == _field(r, "X") % n and _field(l, "Z") == _field(r, "Z") % n

@@ -1,6 +1,7 @@
-"""Stage 1 modulo 2^k - 1 for N | 2^k - 1 (the "F-form" multiply, csrc/gecm_field.hpp; the reference's
-isMersenne == 1 inputs).  The kernel runs the same REDC with the same digits modulo Mw = 2^k - 1 and the
-host reduces modulo N, so the save lines must be byte-identical to the generic path's for every curve."""
+"""Stage 1 modulo 2^k -/+ 1 for N | 2^k -/+ 1 (the "F-form" / "P-form" multiplies, csrc/gecm_field.hpp; the
+reference's isMersenne == +1 / -1 inputs).  The kernel runs the same REDC with the same digits modulo
+Mw = 2^k -/+ 1 and the host reduces modulo N, so the save lines must be byte-identical to the generic
+path's for every curve."""
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -20,9 +21,11 @@ def _lines(n, sig, b1, special):
     return lines, facs, avail, used
 
 
-@pytest.mark.parametrize("k,cof", [(170, 1), (251, 503 * 54217), (401, 1), (521, 1), (607, 1), (701, 1), (929, 1), (1009, 1)])
+@pytest.mark.parametrize("k,cof", [(170, 1), (251, 503 * 54217), (401, 1), (521, 1), (607, 1), (701, 1), (929, 1), (1009, 1),
+                                   (-171, 3), (-256, 1), (-401, 3), (-523, 3), (-600, 1), (-809, 3), (-1024, 1)])
 def test_special_form_stage1_equals_generic_path(k, cof):
-    n = ((1 << k) - 1) // cof
+    n = (((1 << k) - 1) if k > 0 else ((1 << -k) + 1)) // cof
+    assert (((1 << abs(k)) - (1 if k > 0 else -1)) % cof) == 0
     sig = list(range(2000, 2070))
     a, fa, avail, used = _lines(n, sig, 3000, True)
     assert avail[0] and avail[1] == k and used, (avail, used)
