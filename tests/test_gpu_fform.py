@@ -67,3 +67,27 @@ def test_special_form_survives_a_second_stage1_and_stage2():
         out[special] = (lines, eng.download_acc())
         eng.close()
     assert out[True] == out[False]
+
+
+@pytest.mark.parametrize("k", [401, -523])
+def test_special_form_through_upload_points(k):
+    """phase 0 by the caller (gecm_upload_points, operands in the reference's Montgomery radix): the points
+    are lifted to the 2^k -/+ 1 context as well, and come back in the reference's radix modulo N"""
+    import random
+    import pyecm
+    n = (1 << k) - 1 if k > 0 else ((1 << -k) + 1) // 3
+    rng = random.Random(k)
+    xs = [rng.randrange(1, n) for _ in range(40)]
+    ss = [rng.randrange(1, n) for _ in range(40)]
+    out = {}
+    for special in (True, False):
+        eng = pyecm.Engine(n)
+        R = 1 << eng.cfg.maxbits
+        eng.set_special_form(special)
+        eng.upload_points([x * R % n for x in xs], [R % n] * 40, [s * R % n for s in ss])
+        eng.stage1(700)
+        assert eng.special_form()[0] == special
+        out[special] = (eng.download_points(), eng.download_points_plain())
+        eng.close()
+    assert out[True] == out[False]
+    assert all(v < n for v in out[True][0][0] + out[True][0][1])
