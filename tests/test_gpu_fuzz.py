@@ -1,0 +1,71 @@
+"""Seeded differential fuzz on the GPU: random moduli (random odd N of 64..1030 bits, and Cunningham forms
+2^k -/+ 1 with random small cofactors removed), random B1 and sigma; every kernel flavour of stage 1 — one
+and two lanes per curve, generic and special-form multiply — must write the save lines of the oracle
+(oracle/ecm_oracle.c, itself pinned to the reference's outputs)."""
+import ctypes
+import os
+import random
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def orc():
+    L = ctypes.CDLL(os.path.join(ROOT, "oracle", "libecm_oracle.so"))
+    L.orc_create.restype = ctypes.c_void_p
+    L.orc_create.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    L.orc_destroy.argtypes = [ctypes.c_void_p]
+    L.orc_stage1_line.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_char_p, ctypes.c_size_t,
+                                  ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint64)]
+    return L
+
+
+def _cases():
+    rng = random.Random(20261004)
+    out = []
+    for i in range(36):
+        kind = i % 3
+        if kind == 0:
+            bits = rng.randrange(64, 1031)
+            n = rng.getrandbits(bits) | (1 << (bits - 1)) | 1
+            name = "rand%d" % bits
+        else:
+            k = rng.randrange(170, 1025)
+            n = (1 << k) - 1 if kind == 1 else (1 << k) + 1
+            for p in (3, 5, 7, 11, 13, 17, 31, 127, 257):       # divide out some small factors, as users do
+                while n % p == 0 and rng.random() < 0.7:
+                    n //= p
+            name = "2^%d%s1" % (k, "-" if kind == 1 else "+")
+        out.append((name, n, rng.randrange(10, 1500), rng.randrange(6, 1 << 62), rng.choice((52, 32)) if n.bit_length() < 1000 else 32))
+    return out
+
+
+CASES = _cases()
+
+
+@pytest.mark.parametrize("name,n,b1,sigma0,digitbits", CASES, ids=["%02d_%s" % (i, c[0]) for i, c in enumerate(CASES)])
+def test_all_stage1_kernel_flavours_write_the_oracles_lines(orc, name, n, b1, sigma0, digitbits):
+    import pyecm
+    sig = [sigma0 + 7 * j for j in range(9)]
+    c = orc.orc_create(str(n).encode(), digitbits)
+    line = ctypes.create_string_buffer(16384)
+    want = []
+    for s in sig:
+        orc.orc_stage1_line(c, s, b1, line, len(line), None, 0, None)
+        want.append(line.value.decode())
+    orc.orc_destroy(c)
+    eng = pyecm.Engine(n, digitbits=digitbits)
+    special_available = eng.special_form()[1] != 0
+    for special in ((True, False) if special_available else (False,)):
+        for lanes in (1, 2):
+            eng.set_special_form(special)
+            eng.set_lanes_per_curve(lanes)
+            eng.build_curves(sig)
+            eng.stage1(b1)
+            assert eng.lanes_per_curve() == lanes and eng.special_form()[0] == special
+            assert eng.save_lines() == want, (name, special, lanes)
+    eng.close()
