@@ -144,3 +144,45 @@ def test_device_factor_scan_equals_per_curve_host_gcd():
     nf2, first2 = eng.scan_factors(2)
     assert [eng.curve_flag(2, k) for k in range(len(sig))] == host2 and nf2 == sum(host2)
     eng.close()
+
+
+@pytest.mark.parametrize("batch", [40000, 9000])
+def test_sliced_pair_walk_equals_single_accumulator(batch):
+    """A batch that cannot fill the chip walks each run of pairs in several slices with separate
+    accumulators (3 slices for 40000 curves, 14 for 9000 on 256 CUs) merged at the end of the range; the
+    merged accumulator must be the one a single running accumulator gives (GECM_S2_SLICES=1), bit for bit,
+    and the oracle's on the lanes checked."""
+    import ctypes
+    import os
+    import pyecm
+    from conftest import ROOT
+    n = K1N
+    sig = list(range(5000, 5000 + batch))
+    b1, b2, D, U = 200, 60000, 210, 4
+    accs = []
+    for env in (None, "1"):
+        if env is None:
+            os.environ.pop("GECM_S2_SLICES", None)
+        else:
+            os.environ["GECM_S2_SLICES"] = env
+        try:
+            eng = pyecm.Engine(n)
+            eng.build_curves(sig)
+            eng.stage1(b1)
+            eng.stage2(b2, D, U)
+            accs.append(eng.download_acc())
+            eng.close()
+        finally:
+            os.environ.pop("GECM_S2_SLICES", None)
+    assert accs[0] == accs[1]
+    L = ctypes.CDLL(os.path.join(ROOT, "oracle", "libecm_oracle.so"))
+    L.orc_create.restype = ctypes.c_void_p
+    L.orc_create.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    L.orc_stage2.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32,
+                             ctypes.c_uint32, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t,
+                             ctypes.POINTER(ctypes.c_uint64)]
+    c = L.orc_create(str(n).encode(), 52)
+    acch = ctypes.create_string_buffer(8192)
+    for k in (0, 63, 64, batch // 2, batch - 1):
+        L.orc_stage2(c, sig[k], b1, b2, D, U, acch, None, 0, None)
+        assert int(acch.value, 16) == accs[0][k]
