@@ -7,7 +7,8 @@
  *     n!  n#           factorial and primorial (postfix)
  *     << >>            shifts (lowest precedence, as in the reference's table calc.c:1106-1126)
  *     fib(n) luc(n)    Fibonacci and Lucas numbers
- *     gcd(a,b) sqrt(a) modinv(a,m) modexp(a,e,m)
+ *     gcd(a,b) sqrt(a) nroot(a,n) modinv(a,m) modexp(a,e,m) lg2(a) log(a) abs(a) xor(a,b) and(a,b) or(a,b)
+ *                      (lg2 / log = mpz_sizeinbase(a, 2) / (a, 10), calc.c:1250-1259)
  *     ( )              grouping; decimal or 0x-hex literals
  * Values are non-negative and bounded by the mpl capacity (4352 bits); a subtraction that would go
  * negative or an overflow is an error (return code != 0), never a wrong number.
@@ -53,7 +54,7 @@ static void primary(P *p, mpl_t *r)
     } else if (isalpha((unsigned char)*p->s)) {
         char name[8];
         int k = 0;
-        while (isalpha((unsigned char)*p->s) && k < 7) name[k++] = (char)tolower((unsigned char)*p->s++);
+        while (isalnum((unsigned char)*p->s) && k < 7) name[k++] = (char)tolower((unsigned char)*p->s++);   /* lg2 */
         name[k] = 0;
         skip(p);
         if (*p->s != '(') { p->err = 1; return; }
@@ -80,21 +81,48 @@ static void primary(P *p, mpl_t *r)
         } else if (!strcmp(name, "modexp") && na == 3) {
             if (mpl_is_zero(&arg[2])) p->err = 1;
             else mpl_powmod(r, &arg[0], &arg[1], &arg[2]);
-        } else if (!strcmp(name, "sqrt") && na == 1) {
-            /* integer square root by bisection on the bit length */
-            mpl_t lo, hi, mid, sq, one;
+        } else if ((!strcmp(name, "sqrt") && na == 1) || (!strcmp(name, "nroot") && na == 2)) {
+            /* integer k-th root by bisection on the bit length (mpz_sqrt / mpz_root, calc.c:1306, 1322) */
+            uint64_t kth = 2;
+            if (na == 2) {
+                if (arg[1].n > 1 || mpl_get_u64(&arg[1]) < 1 || mpl_get_u64(&arg[1]) > 4096) { p->err = 1; return; }
+                kth = mpl_get_u64(&arg[1]);
+            }
+            mpl_t lo, hi, mid, pw, one;
             mpl_set_u64(&lo, 0);
             mpl_set_u64(&one, 1);
-            mpl_shl(&hi, &one, (unsigned)(mpl_bits(&arg[0]) / 2 + 1));
-            while (mpl_cmp(&lo, &hi) < 0) {           /* invariant: lo^2 <= a < (hi+1)^2 */
+            mpl_shl(&hi, &one, (unsigned)(mpl_bits(&arg[0]) / (int)kth + 1));
+            while (mpl_cmp(&lo, &hi) < 0) {           /* invariant: lo^k <= a < (hi+1)^k */
                 mpl_add(&mid, &lo, &hi);
                 mpl_add(&mid, &mid, &one);
                 mpl_shr(&mid, &mid, 1);
-                mpl_mul(&sq, &mid, &mid);
-                if (mpl_cmp(&sq, &arg[0]) <= 0) lo = mid;
+                int over = 0;
+                pw = one;
+                for (uint64_t e = 0; e < kth && !over; e++) {
+                    if (!fits(&pw, &mid)) { over = 1; break; }
+                    mpl_mul(&pw, &pw, &mid);
+                    if (mpl_cmp(&pw, &arg[0]) > 0) over = 1;
+                }
+                if (!over) lo = mid;
                 else mpl_sub(&hi, &mid, &one);
             }
             *r = lo;
+        } else if (!strcmp(name, "lg2") && na == 1) {
+            mpl_set_u64(r, mpl_is_zero(&arg[0]) ? 1 : (uint64_t)mpl_bits(&arg[0]));
+        } else if (!strcmp(name, "log") && na == 1) {
+            mpl_set_u64(r, (uint64_t)mpl_sizeinbase10(&arg[0]));
+        } else if (!strcmp(name, "abs") && na == 1) {
+            *r = arg[0];
+        } else if ((!strcmp(name, "xor") || !strcmp(name, "and") || !strcmp(name, "or")) && na == 2) {
+            mpl_t o;
+            const int n = arg[0].n > arg[1].n ? arg[0].n : arg[1].n;
+            for (int i = 0; i < n; i++) {
+                const uint32_t x = i < arg[0].n ? arg[0].d[i] : 0, y = i < arg[1].n ? arg[1].d[i] : 0;
+                o.d[i] = name[0] == 'x' ? (x ^ y) : name[0] == 'a' ? (x & y) : (x | y);
+            }
+            o.n = n;
+            while (o.n > 0 && o.d[o.n - 1] == 0) o.n--;
+            *r = o;
         } else {
             p->err = 1;
         }

@@ -165,7 +165,12 @@ def gen_inputs():
     cof251 = (2 ** 251 - 1) // 503 // 54217    # cofactor of M251: the reference folds modulo 2^251 - 1
     exprs = [str(redc), str(cof251), "2^210-1", "2^300+1", "2^251-1", "2^1009-1", "2^945+1", "2^127-1",
              "(2^61-1)*(2^89-1)", "2^1155-1", "2^64+13", "2^400-593", "11526466273339081241",
-             "fib(791)/13/677/216416017", "(2^499-1)/20959", "(2^523+1)/3"]
+             "fib(791)/13/677/216416017", "(2^499-1)/20959", "(2^523+1)/3",
+             # the calculator (calc.c): functions and precedence
+             "nroot(10^300,3)+1", "nroot(2^500+12345,7)*2+1", "lg2(2^400)*2^200+1", "log(10^77)*10^50+1",
+             "xor(2^200+5,2^100+2)", "and(2^200-1,2^150+2^60+1)", "or(2^120,2^60+1)", "abs(2^150+1)", "sqrt(10^100+7)+3",
+             "modinv(17,2^200+1)*2+1", "modexp(3,10^40,2^255-19)", "gcd(fib(601)*3,fib(900)*3)", "100!+1", "149#+1",
+             "(2^300>>100)+1", "(1<<250)+1", "luc(401)", "7^180 % 10^120 + 10^121", "2^2^3+1", "(10^59-1)/9"]
     exe = os.path.join(REFDIR, "avx-ecm-52")
     banner, runs = [], []
     for e in exprs:
