@@ -91,3 +91,40 @@ def test_special_form_through_upload_points(k):
         eng.close()
     assert out[True] == out[False]
     assert all(v < n for v in out[True][0][0] + out[True][0][1])
+
+
+BUILT = [8, 10, 12, 14, 15, 17, 19, 21, 23, 26, 28, 30, 32, 34, 37]
+
+
+def _edge_cases():
+    out = []
+    for i, nl in enumerate(BUILT):
+        prev = BUILT[i - 1] if i else 7
+        for sign in (+1, -1):
+            extra = 0 if sign > 0 else 1                      # 2^k + 1 has k+1 bits
+            hi = 28 * nl - 5 - extra                          # largest k this limb count takes
+            lo = 28 * prev - 4 - extra                        # smallest k that needs it: bit k sits in limb prev-1,
+            out.append((nl, sign * hi))                       # the lowest of the top limbs the kernel reads from n[]
+            out.append((nl, sign * lo))
+    return out
+
+
+@pytest.mark.parametrize("nl,k", _edge_cases(), ids=["nl%d_%+d" % c for c in _edge_cases()])
+def test_special_form_at_both_ends_of_every_limb_count(nl, k):
+    """for each built limb count: the largest and the smallest exponent that maps to it, 2^k - 1 and 2^k + 1"""
+    import pyecm
+    n = (1 << k) - 1 if k > 0 else (1 << -k) + 1
+    sig = list(range(4000, 4033))
+    eng = pyecm.Engine(n)
+    avail, kk, limbs = eng.special_form()
+    assert avail and kk == k and limbs == nl, (avail, kk, limbs)
+    out = []
+    for special in (True, False):
+        for lanes in (1, 2):
+            eng.set_special_form(special)
+            eng.set_lanes_per_curve(lanes)
+            eng.build_curves(sig)
+            eng.stage1(1200)
+            out.append(eng.save_lines())
+    eng.close()
+    assert out[0] == out[1] == out[2] == out[3]
