@@ -114,6 +114,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-small-batch", action="store_true")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per curve in stage 1: 0 = library's choice, 1, 2")
+    ap.add_argument("--no-special-form", action="store_true", help="skip the extra 2^401-1 measurement")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; "
                     "gloo only to rehearse the multi-rank control flow on fewer GPUs than ranks)")
     ap.add_argument("--b2", type=int, default=0, help="also time one stage-2 pass to this B2 (reported separately)")
@@ -206,6 +207,25 @@ def main():
         t1 = time.perf_counter() - t1
         small = {"curves": 4096, "value": 4096 / t1, "unit": "curves/s", "ms_per_step": t1 * 1e3,
                  "kernel_ms": eng.last_kernel_ms(), "lanes_per_curve": eng.lanes_per_curve()}
+    special = None
+    if world == 1 and not a.no_special_form and not a.no_small_batch:
+        # not part of the metric: a Mersenne-form modulus (the reference's isMersenne inputs) through the
+        # generic REDC kernel and through the 2^k - 1 multiply, same batch, B1 = 1e5 (parity of the two paths
+        # is tests/test_gpu_fform.py's job; this is the timing)
+        try:
+            e2 = pyecm.Engine((1 << 401) - 1, digitbits=52, device=devno)
+            ms = {}
+            for on in (False, True):
+                e2.set_special_form(on)
+                e2.set_lanes_per_curve(1)
+                e2.build_curves(list(range(1000, 1000 + a.curves)))
+                e2.stage1(100000, sync=True)
+                ms[on] = e2.last_kernel_ms()
+            special = {"N": "2^401-1", "curves": a.curves, "B1": 100000, "generic_redc_kernel_ms": ms[False],
+                       "special_form_kernel_ms": ms[True], "speedup": ms[False] / ms[True]}
+            e2.close()
+        except Exception as ex:                 # the extra must never cost the headline line
+            special = {"error": str(ex)}
     if rank == 0:
         total_curves = a.curves * world * a.steps
         value = total_curves / dt
@@ -253,6 +273,8 @@ def main():
             line["batch_4096"] = small
         if stage2:
             line["stage2"] = stage2
+        if special:
+            line["special_form"] = special
         if not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(n, a.b1)
         print(json.dumps(line), flush=True)
