@@ -52,6 +52,7 @@ struct gecm_dev {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_ms = 0.f;
     bool timed = false;
+    uint32_t *dModQ = nullptr;   // N and K' limbs padded to 16 each, for the eight-lane kernel (nl <= 16)
     int fform = 0;        // +1 / -1: modulus is 2^k - 1 / 2^k + 1 and stage 1 uses the special multiply (gecm_dev_set_fform)
     int cus = 0;          // compute units of the device (4 SIMDs each)
     int last_lanes = 0;   // lanes per curve the last stage-1 launch used
@@ -102,6 +103,15 @@ extern "C" int gecm_dev_open(gecm_dev **out, int device, int nl, const uint32_t 
     d->kp.assign(kp, kp + nl);
     d->one.assign(one, one + nl);
     d->rho = rho;
+    if (nl <= 16) {
+        uint32_t h[32] = {0};
+        for (int i = 0; i < nl; i++) {
+            h[i] = n[i];
+            h[16 + i] = kp[i];
+        }
+        HIPCHK(hipMalloc(&d->dModQ, sizeof h));
+        HIPCHK(hipMemcpy(d->dModQ, h, sizeof h, hipMemcpyHostToDevice));
+    }
     HIPCHK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
     HIPCHK(hipEventCreate(&d->ev0));
     HIPCHK(hipEventCreate(&d->ev1));
@@ -129,6 +139,7 @@ extern "C" void gecm_dev_close(gecm_dev *d)
     (void)hipSetDevice(d->device);
     free_state(d);
     free_s2(d);
+    (void)hipFree(d->dModQ);
     (void)hipFree(d->dKeep);
     (void)hipFree(d->dSteps);
     (void)hipFree(d->dFlags);
@@ -260,8 +271,12 @@ extern "C" int gecm_dev_stage1(gecm_dev *d, int lanes_per_curve)
         return -2;
     }
     if (lanes_per_curve == 0) lanes_per_curve = gecm_dev_auto_lanes(d);
-    if (lanes_per_curve != 1 && lanes_per_curve != 2) {
-        g_err = "gecm_dev_stage1: lanes per curve must be 0 (auto), 1 or 2";
+    if (lanes_per_curve != 1 && lanes_per_curve != 2 && lanes_per_curve != 8) {
+        g_err = "gecm_dev_stage1: lanes per curve must be 0 (auto), 1, 2 or 8";
+        return -2;
+    }
+    if (lanes_per_curve == 8 && (d->fform || !d->dModQ)) {
+        g_err = "gecm_dev_stage1: no eight-lane kernel for this modulus";
         return -2;
     }
     d->last_lanes = lanes_per_curve;
@@ -270,7 +285,13 @@ extern "C" int gecm_dev_stage1(gecm_dev *d, int lanes_per_curve)
     switch (d->nl) {
 #define X(n)                                                                                     \
     case n:                                                                                      \
-        if (d->fform)                                                                            \
+        if (lanes_per_curve == 8) {                                                              \
+            if (gecm_launch_stage1_quad_##n(d->stream, &mc, d->dTape, (uint32_t)d->tape_len,     \
+                                            d->dX, d->dZ, d->dS, d->stride, d->dModQ)) {         \
+                g_err = "gecm_dev_stage1: no eight-lane kernel for this limb count";             \
+                return -2;                                                                       \
+            }                                                                                    \
+        } else if (d->fform)                                                                     \
             gecm_launch_stage1_f_##n(d->stream, &mc, d->dTape, (uint32_t)d->tape_len, d->dX,     \
                                      d->dZ, d->dS, d->stride, lanes_per_curve, d->fform);       \
         else if (lanes_per_curve == 2)                                                           \

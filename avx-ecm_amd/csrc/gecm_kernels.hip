@@ -5,6 +5,7 @@
 #include "gecm_launch.h"
 #include "gecm_curve.hpp"
 #include "gecm_stage2.hpp"
+#include "gecm_quad.hpp"
 #include <hip/hip_runtime.h>
 
 #ifndef GECM_NL
@@ -109,6 +110,50 @@ k_stage1_pair_f(const uint32_t *__restrict__ tape, uint32_t tape_len, uint32_t *
     Fe<NL> o;
     fe_canonical_mont(o, P, a.one, a.m);
     fe_store(mine, stride, cidx, o);
+}
+
+// Eight lanes per curve (gecm_quad.hpp): built for the limb counts of GECM_QUAD_NLS only.
+#define GECM_HAS_QUAD (GECM_NL == 15)
+#if GECM_HAS_QUAD
+template <int NL>
+__global__ void __launch_bounds__(64, 2)
+k_stage1_quad(const uint32_t *__restrict__ tape, uint32_t tape_len, uint32_t *__restrict__ X,
+              uint32_t *__restrict__ Z, const uint32_t *__restrict__ S, size_t stride, const uint32_t *__restrict__ modq,
+              uint32_t rho)
+{
+    const uint32_t cidx = blockIdx.x * 8u + (threadIdx.x >> 3);
+    const uint32_t l = threadIdx.x & 3u;
+    const bool isZ = (threadIdx.x & 4u) != 0;
+    uint32_t *mine = isZ ? Z : X;
+    QuadMod<NL> m;
+#pragma unroll
+    for (int t = 0; t < 4; t++) {          // modq: [n limbs 0..15 | K' limbs 0..15], zero padded
+        m.n[t] = modq[4 * l + t];
+        m.kp[t] = modq[16 + 4 * l + t];
+    }
+    m.rho = rho;
+    m.is0 = l == 0;
+    m.top_mask = l == 3 ? 0u : 0xffffffffu;
+    FeQ P;
+    feq_load<NL>(P, mine, stride, cidx, l);
+    run_tape_quad<NL>(tape, tape_len, P, S, stride, cidx, l, isZ, m);
+    feq_store<NL>(mine, stride, cidx, l, P);    // lazy representative; k_canon makes it canonical
+}
+#endif
+
+// canonical Montgomery form of X, Z in place (the tail of k_stage1, for kernels that leave lazy values)
+template <int NL>
+__global__ void __launch_bounds__(64)
+k_canon(uint32_t *__restrict__ X, uint32_t *__restrict__ Z, size_t stride, ModArgs<NL> a)
+{
+    uint32_t idx = blockIdx.x * 64u + threadIdx.x;
+    Fe<NL> x, z, r;
+    fe_load(x, X, stride, idx);
+    fe_load(z, Z, stride, idx);
+    fe_canonical_mont(r, x, a.one, a.m);
+    fe_store(X, stride, idx, r);
+    fe_canonical_mont(r, z, a.one, a.m);
+    fe_store(Z, stride, idx, r);
 }
 
 template <int NL>
@@ -296,6 +341,25 @@ extern "C" void CAT(gecm_launch_stage1_pair_, GECM_NL)(void *stream, const gecm_
 {
     hipLaunchKernelGGL(k_stage1_pair<GECM_NL>, dim3((unsigned)(stride / 32)), dim3(64), 0, (hipStream_t)stream,
                        tape, tape_len, X, Z, S, stride, make_args<GECM_NL>(mc));
+}
+
+/* returns 0 if launched, -1 if this limb count has no eight-lane kernel.  modq = device array of 32 words:
+ * limbs 0..15 of N then of K' (zero padded), read per lane. */
+extern "C" int CAT(gecm_launch_stage1_quad_, GECM_NL)(void *stream, const gecm_modconst *mc, const uint32_t *tape,
+                                                      uint32_t tape_len, uint32_t *X, uint32_t *Z,
+                                                      const uint32_t *S, size_t stride, const uint32_t *modq)
+{
+#if GECM_HAS_QUAD
+    static_assert(GECM_NL <= 16, "quad kernel: 4 limbs per lane");
+    hipLaunchKernelGGL(k_stage1_quad<GECM_NL>, dim3((unsigned)(stride / 8)), dim3(64), 0, (hipStream_t)stream, tape,
+                       tape_len, X, Z, S, stride, modq, mc->rho);
+    hipLaunchKernelGGL(k_canon<GECM_NL>, dim3((unsigned)(stride / 64)), dim3(64), 0, (hipStream_t)stream, X, Z, stride,
+                       make_args<GECM_NL>(mc));
+    return 0;
+#else
+    (void)stream; (void)mc; (void)tape; (void)tape_len; (void)X; (void)Z; (void)S; (void)stride; (void)modq;
+    return -1;
+#endif
 }
 
 extern "C" void CAT(gecm_launch_from_mont_, GECM_NL)(void *stream, const gecm_modconst *mc, const uint32_t *X,

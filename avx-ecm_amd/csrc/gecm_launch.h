@@ -49,6 +49,9 @@ typedef struct {
     void gecm_launch_stage1_f_##nl(void *stream, const gecm_modconst *mc, const uint32_t *tape,           \
                                    uint32_t tape_len, uint32_t *X, uint32_t *Z, const uint32_t *S,        \
                                    size_t stride, int lanes, int form);                                   \
+    int gecm_launch_stage1_quad_##nl(void *stream, const gecm_modconst *mc, const uint32_t *tape,         \
+                                     uint32_t tape_len, uint32_t *X, uint32_t *Z, const uint32_t *S,      \
+                                     size_t stride, const uint32_t *modq);                                \
     int gecm_fform_generic_limbs_##nl(void);                                                              \
     void gecm_launch_from_mont_##nl(void *stream, const gecm_modconst *mc, const uint32_t *X,             \
                                     const uint32_t *Z, uint32_t *ox, uint32_t *oz, size_t stride);        \

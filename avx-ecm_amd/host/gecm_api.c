@@ -677,7 +677,7 @@ int gecm_stage1(gecm_ctx *c, uint64_t B1)
             if (gecm_dev_set_tape(c->dev_f, c->tape.ops, c->tape.len)) { set_err("%s", gecm_dev_error()); return GECM_ERR_DEVICE; }
             c->ff_tape_B1 = B1;
         }
-        if (gecm_dev_stage1(c->dev_f, c->lanes_per_curve)) { set_err("%s", gecm_dev_error()); return GECM_ERR_DEVICE; }
+        if (gecm_dev_stage1(c->dev_f, c->lanes_per_curve == 8 ? 0 : c->lanes_per_curve)) { set_err("%s", gecm_dev_error()); return GECM_ERR_DEVICE; }
         c->ff_pending = 1;
         c->last_on_f = 1;
         return GECM_OK;
@@ -705,7 +705,7 @@ int gecm_get_special_form(const gecm_ctx *c, int *k, int *limbs)
 
 int gecm_set_lanes_per_curve(gecm_ctx *c, int lanes)
 {
-    if (!c || lanes < 0 || lanes > 2) { set_err("gecm_set_lanes_per_curve: lanes must be 0 (auto), 1 or 2"); return GECM_ERR_ARG; }
+    if (!c || (lanes != 0 && lanes != 1 && lanes != 2 && lanes != 8)) { set_err("gecm_set_lanes_per_curve: lanes must be 0 (auto), 1, 2 or 8"); return GECM_ERR_ARG; }
     c->lanes_per_curve = lanes;
     return GECM_OK;
 }
