@@ -52,7 +52,7 @@ struct gecm_dev {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_ms = 0.f;
     bool timed = false;
-    uint32_t *dModQ = nullptr;   // N and K' limbs padded to 16 each, for the eight-lane kernel (nl <= 16)
+    uint32_t *dModQ = nullptr;   // N and K' limbs padded to 40 each, for the eight-lane kernel
     int fform = 0;        // +1 / -1: modulus is 2^k - 1 / 2^k + 1 and stage 1 uses the special multiply (gecm_dev_set_fform)
     int cus = 0;          // compute units of the device (4 SIMDs each)
     int last_lanes = 0;   // lanes per curve the last stage-1 launch used
@@ -103,11 +103,11 @@ extern "C" int gecm_dev_open(gecm_dev **out, int device, int nl, const uint32_t 
     d->kp.assign(kp, kp + nl);
     d->one.assign(one, one + nl);
     d->rho = rho;
-    if (nl <= 16) {
-        uint32_t h[32] = {0};
+    if (nl <= 40) {
+        uint32_t h[80] = {0};
         for (int i = 0; i < nl; i++) {
             h[i] = n[i];
-            h[16 + i] = kp[i];
+            h[40 + i] = kp[i];
         }
         HIPCHK(hipMalloc(&d->dModQ, sizeof h));
         HIPCHK(hipMemcpy(d->dModQ, h, sizeof h, hipMemcpyHostToDevice));
@@ -243,6 +243,11 @@ extern "C" int gecm_dev_set_tape(gecm_dev *d, const uint8_t *tape, size_t len)
  * equal at 23 — tools/lanes_sizes.py, interleaved runs). */
 extern "C" int gecm_dev_auto_lanes(gecm_dev *d)
 {
+    /* a batch that cannot even put one two-lane wavefront on every SIMD: eight lanes per curve (X and Z on two
+     * quads, the limbs of a residue spread over the quad, csrc/gecm_quad.hpp) — 1.5x the two-lane layout at 15
+     * limbs, 2.2-2.4x at 30-37 limbs, up to 32 curves per CU; from 19 limbs up still 1.2-1.4x at 64 curves
+     * per CU (tools/quad_check.py).  Generic moduli only. */
+    if (!d->fform && d->dModQ && d->stride <= (size_t)d->cus * (d->nl >= 19 ? 64 : 32)) return 8;
     if (d->nl >= 26) return 2;
     const size_t full = (size_t)d->cus * 4 * 128;
     const size_t r = d->stride % full;

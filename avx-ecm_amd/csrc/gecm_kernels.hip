@@ -112,8 +112,8 @@ k_stage1_pair_f(const uint32_t *__restrict__ tape, uint32_t tape_len, uint32_t *
     fe_store(mine, stride, cidx, o);
 }
 
-// Eight lanes per curve (gecm_quad.hpp): built for the limb counts of GECM_QUAD_NLS only.
-#define GECM_HAS_QUAD (GECM_NL == 15)
+// Eight lanes per curve (gecm_quad.hpp).
+#define GECM_HAS_QUAD 1
 #if GECM_HAS_QUAD
 template <int NL>
 __global__ void __launch_bounds__(64, 2)
@@ -125,16 +125,17 @@ k_stage1_quad(const uint32_t *__restrict__ tape, uint32_t tape_len, uint32_t *__
     const uint32_t l = threadIdx.x & 3u;
     const bool isZ = (threadIdx.x & 4u) != 0;
     uint32_t *mine = isZ ? Z : X;
+    constexpr int NQ = QuadShape<NL>::NQ;
     QuadMod<NL> m;
 #pragma unroll
-    for (int t = 0; t < 4; t++) {          // modq: [n limbs 0..15 | K' limbs 0..15], zero padded
-        m.n[t] = modq[4 * l + t];
-        m.kp[t] = modq[16 + 4 * l + t];
+    for (int t = 0; t < NQ; t++) {         // modq: [n limbs 0..39 | K' limbs 0..39], zero padded
+        m.n[t] = modq[NQ * l + t];
+        m.kp[t] = modq[40 + NQ * l + t];
     }
     m.rho = rho;
     m.is0 = l == 0;
     m.top_mask = l == 3 ? 0u : 0xffffffffu;
-    FeQ P;
+    FeQn<NQ> P;
     feq_load<NL>(P, mine, stride, cidx, l);
     run_tape_quad<NL>(tape, tape_len, P, S, stride, cidx, l, isZ, m);
     feq_store<NL>(mine, stride, cidx, l, P);    // lazy representative; k_canon makes it canonical
@@ -343,14 +344,13 @@ extern "C" void CAT(gecm_launch_stage1_pair_, GECM_NL)(void *stream, const gecm_
                        tape, tape_len, X, Z, S, stride, make_args<GECM_NL>(mc));
 }
 
-/* returns 0 if launched, -1 if this limb count has no eight-lane kernel.  modq = device array of 32 words:
- * limbs 0..15 of N then of K' (zero padded), read per lane. */
+/* returns 0 if launched, -1 if this limb count has no eight-lane kernel.  modq = device array of 80 words:
+ * limbs 0..39 of N then of K' (zero padded), read per lane. */
 extern "C" int CAT(gecm_launch_stage1_quad_, GECM_NL)(void *stream, const gecm_modconst *mc, const uint32_t *tape,
                                                       uint32_t tape_len, uint32_t *X, uint32_t *Z,
                                                       const uint32_t *S, size_t stride, const uint32_t *modq)
 {
 #if GECM_HAS_QUAD
-    static_assert(GECM_NL <= 16, "quad kernel: 4 limbs per lane");
     hipLaunchKernelGGL(k_stage1_quad<GECM_NL>, dim3((unsigned)(stride / 8)), dim3(64), 0, (hipStream_t)stream, tape,
                        tape_len, X, Z, S, stride, modq, mc->rho);
     hipLaunchKernelGGL(k_canon<GECM_NL>, dim3((unsigned)(stride / 64)), dim3(64), 0, (hipStream_t)stream, X, Z, stride,

@@ -1,5 +1,6 @@
 // gecm_quad.hpp — stage 1 with EIGHT lanes per curve: the X and the Z coordinate of a curve's points on two
-// adjacent quads of lanes, and inside a quad each lane holds 4 of the residue's limbs (lane l: limbs 4l..4l+3).
+// adjacent quads of lanes, and inside a quad each lane holds NQ = ceil(NL/4) of the residue's limbs (lane l:
+// limbs NQ*l .. NQ*l+NQ-1).
 //
 // For batches of a few thousand curves (BASELINE configs[1]: 4096) even two lanes per curve leave 7 SIMDs of
 // 8 without a wavefront.  The last place left to split is the multiplication itself.  It is done row-wise
@@ -15,14 +16,20 @@
 #pragma once
 #include "gecm_curve.hpp"
 
-struct FeQ {
-    uint32_t v[4];
+template <int NL>
+struct QuadShape {
+    static constexpr int NQ = (NL + 3) / 4;      // limbs per lane: lane l of a quad holds limbs NQ*l .. NQ*l+NQ-1
+};
+
+template <int NQ>
+struct FeQn {
+    uint32_t v[NQ];
 };
 
 template <int NL>
 struct QuadMod {
-    uint32_t n[4];    // this lane's limbs of N
-    uint32_t kp[4];   // this lane's limbs of K'
+    uint32_t n[QuadShape<NL>::NQ];    // this lane's limbs of N
+    uint32_t kp[QuadShape<NL>::NQ];   // this lane's limbs of K'
     uint32_t rho;
     uint32_t top_mask;   // 0 on the last lane of the quad, ~0 elsewhere
     bool is0;            // first lane of the quad
@@ -46,52 +53,86 @@ __device__ __forceinline__ uint32_t other_coord(uint32_t x)       // lane <-> la
     return (uint32_t)__builtin_amdgcn_ds_swizzle((int)x, 0x101F /* bit mode: and 0x1f, or 0, xor 4 */);
 }
 
-// four accumulators, one multiplier: T[j] += x * y[j]
-__device__ __forceinline__ void mad4(uint64_t &t0, uint64_t &t1, uint64_t &t2, uint64_t &t3, uint32_t x, const uint32_t (&y)[4])
+// T[j] += x * y[j] for 1..4 accumulators in one asm statement
+__device__ __forceinline__ void mad1(uint64_t &t0, uint32_t x, uint32_t y0)
+{
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(t0) : "v"(x), "v"(y0) : "vcc");
+}
+__device__ __forceinline__ void mad2(uint64_t &t0, uint64_t &t1, uint32_t x, uint32_t y0, uint32_t y1)
+{
+    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_mad_u64_u32 %1, vcc, %2, %4, %1" : "+v"(t0), "+v"(t1) : "v"(x), "v"(y0), "v"(y1) : "vcc");
+}
+__device__ __forceinline__ void mad3(uint64_t &t0, uint64_t &t1, uint64_t &t2, uint32_t x, uint32_t y0, uint32_t y1, uint32_t y2)
+{
+    asm("v_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_mad_u64_u32 %1, vcc, %3, %5, %1\n\tv_mad_u64_u32 %2, vcc, %3, %6, %2"
+        : "+v"(t0), "+v"(t1), "+v"(t2) : "v"(x), "v"(y0), "v"(y1), "v"(y2) : "vcc");
+}
+__device__ __forceinline__ void mad4(uint64_t &t0, uint64_t &t1, uint64_t &t2, uint64_t &t3, uint32_t x, uint32_t y0, uint32_t y1,
+                                     uint32_t y2, uint32_t y3)
 {
     asm("v_mad_u64_u32 %0, vcc, %4, %5, %0\n\tv_mad_u64_u32 %1, vcc, %4, %6, %1\n\t"
         "v_mad_u64_u32 %2, vcc, %4, %7, %2\n\tv_mad_u64_u32 %3, vcc, %4, %8, %3"
-        : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3)
-        : "v"(x), "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3])
-        : "vcc");
+        : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3) : "v"(x), "v"(y0), "v"(y1), "v"(y2), "v"(y3) : "vcc");
+}
+
+// one row: T[(t + ROT) % NQ] += x * y[t] for t = T0 .. NQ-1
+template <int NQ, int ROT, int T0 = 0>
+__device__ __forceinline__ void mad_row(uint64_t (&T)[NQ], uint32_t x, const uint32_t (&y)[NQ])
+{
+    constexpr int left = NQ - T0;
+    if constexpr (left >= 4) {
+        mad4(T[(T0 + ROT) % NQ], T[(T0 + 1 + ROT) % NQ], T[(T0 + 2 + ROT) % NQ], T[(T0 + 3 + ROT) % NQ], x, y[T0], y[T0 + 1],
+             y[T0 + 2], y[T0 + 3]);
+        mad_row<NQ, ROT, T0 + 4>(T, x, y);
+    } else if constexpr (left == 3) {
+        mad3(T[(T0 + ROT) % NQ], T[(T0 + 1 + ROT) % NQ], T[(T0 + 2 + ROT) % NQ], x, y[T0], y[T0 + 1], y[T0 + 2]);
+    } else if constexpr (left == 2) {
+        mad2(T[(T0 + ROT) % NQ], T[(T0 + 1 + ROT) % NQ], x, y[T0], y[T0 + 1]);
+    } else if constexpr (left == 1) {
+        mad1(T[(T0 + ROT) % NQ], x, y[T0]);
+    }
 }
 
 // r = a*b/R mod N (lazy, limbs < 2^28): the same integer fe_mul<NL> returns.
 template <int NL>
-__device__ __forceinline__ void feq_mul(FeQ &r, const FeQ &a, const FeQ &b, const QuadMod<NL> &m)
+__device__ __forceinline__ void feq_mul(FeQn<QuadShape<NL>::NQ> &r, const FeQn<QuadShape<NL>::NQ> &a,
+                                        const FeQn<QuadShape<NL>::NQ> &b, const QuadMod<NL> &m)
 {
-    uint64_t T[4] = {0, 0, 0, 0};
+    constexpr int NQ = QuadShape<NL>::NQ;
+    uint64_t T[NQ];
+#pragma unroll
+    for (int t = 0; t < NQ; t++) T[t] = 0;
     static_for<0, NL>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
-        // logical slot t of the window lives in T[(t + i) % 4]
-        const uint32_t ai = quad_bcast<i / 4>(a.v[i % 4]);
-        mad4(T[(0 + i) % 4], T[(1 + i) % 4], T[(2 + i) % 4], T[(3 + i) % 4], ai, b.v);
-        const uint32_t q = quad_bcast<0>(((uint32_t)T[i % 4] * m.rho) & GECM_LIMB_MASK);
-        mad4(T[(0 + i) % 4], T[(1 + i) % 4], T[(2 + i) % 4], T[(3 + i) % 4], q, m.n);
+        constexpr int rot = i % NQ;                       // logical slot t of the window lives in T[(t + i) % NQ]
+        const uint32_t ai = quad_bcast<i / NQ>(a.v[i % NQ]);
+        mad_row<NQ, rot>(T, ai, b.v);
+        const uint32_t q = quad_bcast<0>(((uint32_t)T[rot] * m.rho) & GECM_LIMB_MASK);
+        mad_row<NQ, rot>(T, q, m.n);
         // the window moves down one limb: every lane folds the part of its lowest accumulator that lies above
         // 28 bits into its next one (it has that weight) and hands the low 28 bits to the lane below, whose
         // new top slot they are.  Lane 0's low 28 bits are zero by construction of q and go nowhere.
-        const uint64_t old0 = T[i % 4];
-        T[(i + 1) % 4] += old0 >> GECM_LIMB_BITS;
+        const uint64_t old0 = T[rot];
+        T[(1 + i) % NQ] += old0 >> GECM_LIMB_BITS;
         const uint32_t lo = quad_from_above((uint32_t)old0 & GECM_LIMB_MASK);
-        T[i % 4] = (uint64_t)(lo & m.top_mask);                                      // new top slot (0 on lane 3)
+        T[rot] = (uint64_t)(lo & m.top_mask);                                         // new top slot (0 on lane 3)
     });
     // carry propagation to limbs < 2^28: inside the lane, then one hand-over to the lane above, then
     // (almost never) single-bit ripples until no lane has a carry left
     uint64_t carry = 0;
-    uint32_t o[4];
-#pragma unroll
-    for (int t = 0; t < 4; t++) {
-        const uint64_t v = T[(t + NL) % 4] + carry;
+    uint32_t o[NQ];
+    static_for<0, NQ>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        const uint64_t v = T[(t + NL) % NQ] + carry;
         o[t] = (uint32_t)v & GECM_LIMB_MASK;
         carry = v >> GECM_LIMB_BITS;
-    }
+    });
     uint32_t clo = quad_from_below((uint32_t)carry), chi = quad_from_below((uint32_t)(carry >> 32));
     uint64_t cin = m.is0 ? 0ull : (((uint64_t)chi << 32) | clo);
     for (;;) {
         uint64_t c = cin;
 #pragma unroll
-        for (int t = 0; t < 4; t++) {
+        for (int t = 0; t < NQ; t++) {
             const uint64_t v = (uint64_t)o[t] + c;
             o[t] = (uint32_t)v & GECM_LIMB_MASK;
             c = v >> GECM_LIMB_BITS;
@@ -102,115 +143,142 @@ __device__ __forceinline__ void feq_mul(FeQ &r, const FeQ &a, const FeQ &b, cons
         if (__builtin_amdgcn_ballot_w64(cin != 0) == 0) break;
     }
 #pragma unroll
-    for (int t = 0; t < 4; t++) r.v[t] = o[t];
+    for (int t = 0; t < NQ; t++) r.v[t] = o[t];
+}
+
+// fe_weak_norm across the quad: limbs < 2^30 in, limbs < 2^28 + 4 out, value unchanged (needed above 25 limbs,
+// LazyPolicy, so that accumulator sums stay below 2^64)
+template <int NL>
+__device__ __forceinline__ void feq_weak_norm(FeQn<QuadShape<NL>::NQ> &r, const QuadMod<NL> &m)
+{
+    constexpr int NQ = QuadShape<NL>::NQ;
+    const uint32_t below = quad_from_below(r.v[NQ - 1] >> GECM_LIMB_BITS);     // carry of the lane below's top limb
+    FeQn<NQ> o;
+    o.v[0] = (r.v[0] & GECM_LIMB_MASK) + (m.is0 ? 0u : below);
+#pragma unroll
+    for (int t = 1; t < NQ; t++) o.v[t] = (r.v[t] & GECM_LIMB_MASK) + (r.v[t - 1] >> GECM_LIMB_BITS);
+    // the very top limb of the residue (limb NL-1, on lane 3) keeps its upper bits, as in fe_weak_norm, and
+    // the padding slots above it stay as they are (zero)
+    constexpr int t_top = (NL - 1) - 3 * NQ;
+    static_assert(t_top >= 0 && t_top < NQ, "limb NL-1 must sit on the last lane of the quad");
+    const bool last = m.top_mask == 0u;
+#pragma unroll
+    for (int t = 0; t < NQ; t++) {
+        if (t == t_top) o.v[t] = last ? o.v[t] + (r.v[t] & ~GECM_LIMB_MASK) : o.v[t];
+        else if (t > t_top) o.v[t] = last ? r.v[t] : o.v[t];
+    }
+    r = o;
 }
 
 template <int NL>
-__device__ __forceinline__ void feq_add(FeQ &r, const FeQ &a, const FeQ &b)
+__device__ __forceinline__ void feq_add(FeQn<QuadShape<NL>::NQ> &r, const FeQn<QuadShape<NL>::NQ> &a, const FeQn<QuadShape<NL>::NQ> &b)
 {
 #pragma unroll
-    for (int t = 0; t < 4; t++) r.v[t] = a.v[t] + b.v[t];
+    for (int t = 0; t < QuadShape<NL>::NQ; t++) r.v[t] = a.v[t] + b.v[t];
 }
 
 template <int NL>
-__device__ __forceinline__ void feq_sub(FeQ &r, const FeQ &a, const FeQ &b, const QuadMod<NL> &m)
+__device__ __forceinline__ void feq_sub(FeQn<QuadShape<NL>::NQ> &r, const FeQn<QuadShape<NL>::NQ> &a, const FeQn<QuadShape<NL>::NQ> &b, const QuadMod<NL> &m)
 {
 #pragma unroll
-    for (int t = 0; t < 4; t++) r.v[t] = a.v[t] + m.kp[t] - b.v[t];
+    for (int t = 0; t < QuadShape<NL>::NQ; t++) r.v[t] = a.v[t] + m.kp[t] - b.v[t];
+    if (LazyPolicy<NL>::norm_sub) feq_weak_norm<NL>(r, m);
 }
 
 // r = x + y on lanes with neg == false, x - y + K on lanes with neg == true
 template <int NL>
-__device__ __forceinline__ void feq_addsub_lane(FeQ &r, const FeQ &x, const FeQ &y, bool neg, const QuadMod<NL> &m)
+__device__ __forceinline__ void feq_addsub_lane(FeQn<QuadShape<NL>::NQ> &r, const FeQn<QuadShape<NL>::NQ> &x, const FeQn<QuadShape<NL>::NQ> &y, bool neg, const QuadMod<NL> &m)
 {
 #pragma unroll
-    for (int t = 0; t < 4; t++) {
+    for (int t = 0; t < QuadShape<NL>::NQ; t++) {
         const uint32_t s = neg ? m.kp[t] - y.v[t] : y.v[t];
         r.v[t] = x.v[t] + s;
     }
+    if (LazyPolicy<NL>::norm_sub) feq_weak_norm<NL>(r, m);
 }
 
-__device__ __forceinline__ void feq_other(FeQ &r, const FeQ &a)
+template <int NL>
+__device__ __forceinline__ void feq_other(FeQn<QuadShape<NL>::NQ> &r, const FeQn<QuadShape<NL>::NQ> &a)
 {
 #pragma unroll
-    for (int t = 0; t < 4; t++) r.v[t] = other_coord(a.v[t]);
+    for (int t = 0; t < QuadShape<NL>::NQ; t++) r.v[t] = other_coord(a.v[t]);
 }
 
 // the point arithmetic of gecm_curve.hpp's two-lane layout, on quads
 template <int NL>
-__device__ __forceinline__ void quad_sum_diff(FeQ &r, const FeQ &own, bool isZ, const QuadMod<NL> &m)
+__device__ __forceinline__ void quad_sum_diff(FeQn<QuadShape<NL>::NQ> &r, const FeQn<QuadShape<NL>::NQ> &own, bool isZ, const QuadMod<NL> &m)
 {
-    FeQ oth;
-    feq_other(oth, own);
-    feq_addsub_lane(r, oth, own, isZ, m);          // X lanes: Z + X      Z lanes: X - Z
+    FeQn<QuadShape<NL>::NQ> oth;
+    feq_other<NL>(oth, own);
+    feq_addsub_lane<NL>(r, oth, own, isZ, m);          // X lanes: Z + X      Z lanes: X - Z
 }
 
 template <int NL>
-__device__ __forceinline__ void quad_diff_sum(FeQ &r, const FeQ &own, bool isZ, const QuadMod<NL> &m)
+__device__ __forceinline__ void quad_diff_sum(FeQn<QuadShape<NL>::NQ> &r, const FeQn<QuadShape<NL>::NQ> &own, bool isZ, const QuadMod<NL> &m)
 {
-    FeQ oth;
-    feq_other(oth, own);
-    feq_addsub_lane(r, own, oth, !isZ, m);         // X lanes: X - Z      Z lanes: Z + X
+    FeQn<QuadShape<NL>::NQ> oth;
+    feq_other<NL>(oth, own);
+    feq_addsub_lane<NL>(r, own, oth, !isZ, m);         // X lanes: X - Z      Z lanes: Z + X
 }
 
 template <int NL>
-__device__ __forceinline__ void quad_add(FeQ &T, const FeQ &fB, const FeQ &fA, const FeQ &c, bool isZ, const QuadMod<NL> &m)
+__device__ __forceinline__ void quad_add(FeQn<QuadShape<NL>::NQ> &T, const FeQn<QuadShape<NL>::NQ> &fB, const FeQn<QuadShape<NL>::NQ> &fA, const FeQn<QuadShape<NL>::NQ> &c, bool isZ, const QuadMod<NL> &m)
 {
-    FeQ w, t, e;
-    feq_mul(w, fB, fA, m);                         // X: U      Z: V
-    feq_other(t, w);
-    feq_addsub_lane(e, t, w, isZ, m);              // X: V + U  Z: U - V
-    feq_mul(e, e, e, m);                           // squares (no symmetry saving in the row-wise form)
-    feq_other(t, c);                               // X: C.Z    Z: C.X
-    feq_mul(T, e, t, m);
+    FeQn<QuadShape<NL>::NQ> w, t, e;
+    feq_mul<NL>(w, fB, fA, m);                         // X: U      Z: V
+    feq_other<NL>(t, w);
+    feq_addsub_lane<NL>(e, t, w, isZ, m);              // X: V + U  Z: U - V
+    feq_mul<NL>(e, e, e, m);                           // squares (no symmetry saving in the row-wise form)
+    feq_other<NL>(t, c);                               // X: C.Z    Z: C.X
+    feq_mul<NL>(T, e, t, m);
 }
 
 template <int NL>
-__device__ __forceinline__ void quad_dup(FeQ &D, const FeQ &fA, const FeQ &s4, bool isZ, const QuadMod<NL> &m)
+__device__ __forceinline__ void quad_dup(FeQn<QuadShape<NL>::NQ> &D, const FeQn<QuadShape<NL>::NQ> &fA, const FeQn<QuadShape<NL>::NQ> &s4, bool isZ, const QuadMod<NL> &m)
 {
-    FeQ q, t, w, p1, p2, r1;
-    feq_mul(q, fA, fA, m);                         // X: U = (x+z)^2    Z: V = (x-z)^2
-    feq_other(t, q);                               // X: V              Z: U
-    feq_sub(w, t, q, m);                           // Z: w = U - V
+    FeQn<QuadShape<NL>::NQ> q, t, w, p1, p2, r1;
+    feq_mul<NL>(q, fA, fA, m);                         // X: U = (x+z)^2    Z: V = (x-z)^2
+    feq_other<NL>(t, q);                               // X: V              Z: U
+    feq_sub<NL>(w, t, q, m);                           // Z: w = U - V
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < QuadShape<NL>::NQ; i++) {
         p1.v[i] = isZ ? s4.v[i] : q.v[i];
         p2.v[i] = isZ ? w.v[i] : t.v[i];
     }
-    feq_mul(r1, p1, p2, m);                        // X: U*V            Z: s*w
+    feq_mul<NL>(r1, p1, p2, m);                        // X: U*V            Z: s*w
     feq_add<NL>(t, r1, q);                         // Z: s*w + V
-    feq_mul(t, t, w, m);                           // Z: (s*w + V)*w
+    feq_mul<NL>(t, t, w, m);                           // Z: (s*w + V)*w
 #pragma unroll
-    for (int i = 0; i < 4; i++) D.v[i] = isZ ? t.v[i] : r1.v[i];
+    for (int i = 0; i < QuadShape<NL>::NQ; i++) D.v[i] = isZ ? t.v[i] : r1.v[i];
 }
 
 template <int NL>
-__device__ __forceinline__ void feq_load(FeQ &r, const uint32_t *__restrict__ base, size_t stride, uint32_t cidx, uint32_t l)
+__device__ __forceinline__ void feq_load(FeQn<QuadShape<NL>::NQ> &r, const uint32_t *__restrict__ base, size_t stride, uint32_t cidx, uint32_t l)
 {
 #pragma unroll
-    for (int t = 0; t < 4; t++) {
-        const uint32_t limb = 4 * l + (uint32_t)t;
+    for (int t = 0; t < QuadShape<NL>::NQ; t++) {
+        const uint32_t limb = (uint32_t)QuadShape<NL>::NQ * l + (uint32_t)t;
         r.v[t] = limb < (uint32_t)NL ? base[(size_t)limb * stride + cidx] : 0u;
     }
 }
 
 template <int NL>
-__device__ __forceinline__ void feq_store(uint32_t *__restrict__ base, size_t stride, uint32_t cidx, uint32_t l, const FeQ &r)
+__device__ __forceinline__ void feq_store(uint32_t *__restrict__ base, size_t stride, uint32_t cidx, uint32_t l, const FeQn<QuadShape<NL>::NQ> &r)
 {
 #pragma unroll
-    for (int t = 0; t < 4; t++) {
-        const uint32_t limb = 4 * l + (uint32_t)t;
+    for (int t = 0; t < QuadShape<NL>::NQ; t++) {
+        const uint32_t limb = (uint32_t)QuadShape<NL>::NQ * l + (uint32_t)t;
         if (limb < (uint32_t)NL) base[(size_t)limb * stride + cidx] = r.v[t];
     }
 }
 
 // run_tape_pair of gecm_curve.hpp on quads: A, B, C are this lane's 4 limbs of its coordinate.
 template <int NL>
-__device__ __forceinline__ void run_tape_quad(const uint32_t *__restrict__ tape, uint32_t tape_len, FeQ &A,
+__device__ __forceinline__ void run_tape_quad(const uint32_t *__restrict__ tape, uint32_t tape_len, FeQn<QuadShape<NL>::NQ> &A,
                                               const uint32_t *__restrict__ S, size_t stride, uint32_t cidx, uint32_t l,
                                               bool isZ, const QuadMod<NL> &m)
 {
-    FeQ B = A, C = A;
+    FeQn<QuadShape<NL>::NQ> B = A, C = A;
     auto fetch = [&](uint32_t pc) -> uint32_t {
         uint32_t w = tape[pc >> 2];
         return __builtin_amdgcn_readfirstlane((w >> ((pc & 3u) * 8u)) & 0xffu);
@@ -221,14 +289,14 @@ __device__ __forceinline__ void run_tape_quad(const uint32_t *__restrict__ tape,
         nxt = (pc + 1 < tape_len) ? fetch(pc + 1) : GECM_OP_NOP;
         while ((op & ~GECM_OP_SWAP) == (GECM_OP_STEP | GECM_OP_RULE3)) {
             if (op & GECM_OP_SWAP) {
-                FeQ t = A;
+                FeQn<QuadShape<NL>::NQ> t = A;
                 A = B;
                 B = t;
             }
-            FeQ fA, fB, T;
-            quad_diff_sum(fB, B, isZ, m);
-            quad_sum_diff(fA, A, isZ, m);
-            quad_add(T, fB, fA, C, isZ, m);
+            FeQn<QuadShape<NL>::NQ> fA, fB, T;
+            quad_diff_sum<NL>(fB, B, isZ, m);
+            quad_sum_diff<NL>(fA, A, isZ, m);
+            quad_add<NL>(T, fB, fA, C, isZ, m);
             C = B;
             B = T;
             pc++;
@@ -241,16 +309,16 @@ __device__ __forceinline__ void run_tape_quad(const uint32_t *__restrict__ tape,
         const bool do_add = op != GECM_OP_PRAC_BEGIN;
         const bool do_dup = op != GECM_OP_PRAC_END;
         if (is_step && (op & GECM_OP_SWAP)) {
-            FeQ t = A;
+            FeQn<QuadShape<NL>::NQ> t = A;
             A = B;
             B = t;
         }
         if (is_step && rule == GECM_OP_RULE5) {
-            FeQ t = B;
+            FeQn<QuadShape<NL>::NQ> t = B;
             B = C;
             C = t;
         } else if (is_step && rule == GECM_OP_RULE9) {
-            FeQ t = A;
+            FeQn<QuadShape<NL>::NQ> t = A;
             A = B;
             B = C;
             C = t;
@@ -258,19 +326,19 @@ __device__ __forceinline__ void run_tape_quad(const uint32_t *__restrict__ tape,
             B = A;
             C = A;
         }
-        FeQ T, D;
+        FeQn<QuadShape<NL>::NQ> T, D;
         {
-            FeQ fA;
-            quad_sum_diff(fA, A, isZ, m);
+            FeQn<QuadShape<NL>::NQ> fA;
+            quad_sum_diff<NL>(fA, A, isZ, m);
             if (do_add) {
-                FeQ fB;
-                quad_diff_sum(fB, B, isZ, m);
-                quad_add(T, fB, fA, C, isZ, m);
+                FeQn<QuadShape<NL>::NQ> fB;
+                quad_diff_sum<NL>(fB, B, isZ, m);
+                quad_add<NL>(T, fB, fA, C, isZ, m);
             }
             if (do_dup) {
-                FeQ s4;
+                FeQn<QuadShape<NL>::NQ> s4;
                 feq_load<NL>(s4, S, stride, cidx, l);
-                quad_dup(D, fA, s4, isZ, m);
+                quad_dup<NL>(D, fA, s4, isZ, m);
             }
         }
         if (op == GECM_OP_PRAC_END) {
@@ -281,12 +349,12 @@ __device__ __forceinline__ void run_tape_quad(const uint32_t *__restrict__ tape,
             B = T;
             A = D;
         } else if (rule == GECM_OP_RULE5) {
-            FeQ t = C;
+            FeQn<QuadShape<NL>::NQ> t = C;
             C = T;
             B = t;
             A = D;
         } else {
-            FeQ oldA = C;
+            FeQn<QuadShape<NL>::NQ> oldA = C;
             C = T;
             B = D;
             A = oldA;

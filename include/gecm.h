@@ -122,9 +122,13 @@ int gecm_sync(gecm_ctx *ctx);
  * the Z coordinate of a curve on two adjacent lanes (32 curves per wavefront): each point operation's
  * independent halves (ecm.c:417-440, 447-454) run side by side, so a curve finishes in half the time
  * and a batch fills the chip at half the size (1.83x the curves/s up to 32768 curves on MI355X).
- * 0 (default) = chosen per launch: 1 when the batch's last round of 128 x 4 x CUs curves is more than
- * three quarters full and N is at most 639 bits, else 2.  Results are identical.
+ * 8 = X and Z on two adjacent quads of lanes and the limbs of each residue spread over the four lanes of
+ * its quad (8 curves per wavefront), with a row-wise Montgomery multiply whose digit and operand limbs are
+ * broadcast inside the quad: another 1.5x (416-bit) to 2.4x (1024-bit) for batches up to 8192 curves.
+ * 0 (default) = chosen per launch from the batch size, the limb count and the CU count
+ * (gecm_dev_auto_lanes).  Results are identical in every layout.
  * gecm_get_lanes_per_curve returns what the last gecm_stage1 launch used (0 before the first). */
+int gecm_set_lanes_per_curve(gecm_ctx *ctx, int lanes);
 /* N | 2^k - 1 or N | 2^k + 1 (Cunningham cofactors; the reference's isMersenne == +1 / -1, main.c:410-430, for
  * which it switches to vecmulmod52_mersenne): stage 1 runs modulo 2^k -/+ 1 with a multiply whose reduction
  * half needs almost no multiplications, and X, Z are reduced modulo N when they come back.  Chosen at
@@ -135,7 +139,6 @@ int gecm_sync(gecm_ctx *ctx);
  * form or it would not pay). */
 int gecm_set_special_form(gecm_ctx *ctx, int on);
 int gecm_get_special_form(const gecm_ctx *ctx, int *k, int *limbs);
-int gecm_set_lanes_per_curve(gecm_ctx *ctx, int lanes);
 int gecm_get_lanes_per_curve(const gecm_ctx *ctx);
 /* milliseconds of the last stage-1 kernel, from HIP events on the context's stream */
 double gecm_last_kernel_ms(const gecm_ctx *ctx);

@@ -1,5 +1,5 @@
 """Eight lanes per curve against two lanes per curve: same save lines, kernel times over batch sizes.
-usage: python tools/quad_check.py [B1] [bits]"""
+usage: python tools/quad_check.py [B1] [bits] [batch,batch,...]"""
 import os, sys, random
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "avx-ecm_amd"))
 import pyecm
@@ -8,7 +8,8 @@ bits = int(sys.argv[2]) if len(sys.argv) > 2 else 415
 n = random.Random(bits).getrandbits(bits) | (1 << (bits - 1)) | 1
 eng = pyecm.Engine(n)
 ok = True
-for batch in (8, 70, 1024, 4096, 8192, 16384):
+batches = [int(x) for x in sys.argv[3].split(',')] if len(sys.argv) > 3 else [8, 70, 1024, 4096, 8192, 12288, 16384]
+for batch in batches:
     sig = list(range(1000, 1000 + batch))
     res = {}
     for lanes in (2, 8):
