@@ -198,8 +198,9 @@ def main():
     small = None
     if world == 1 and a.curves != 4096 and not a.no_small_batch:
         # BASELINE.json configs[1] names a 4096-curve batch: with one curve per lane that is 64
-        # wavefronts for 1024 SIMDs, so the library splits each curve over two lanes (128 wavefronts,
-        # each half as long).  Measured separately (one pass) and reported next to `value`.
+        # wavefronts for 1024 SIMDs, so the library spreads each curve over eight lanes (512 wavefronts:
+        # X and Z on two quads, the limbs of a residue over the lanes of its quad).  Measured separately
+        # (one pass) and reported next to `value`.
         eng.build_curves(list(range(1000, 1000 + 4096)))
         eng.set_lanes_per_curve(0)
         t1 = time.perf_counter()

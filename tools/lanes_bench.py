@@ -8,9 +8,8 @@ import pyecm  # noqa: E402
 
 b1 = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
 bits = int(sys.argv[2]) if len(sys.argv) > 2 else 415
-n = (1 << bits) - 1
-while n % 3 == 0 or n % 5 == 0 or n % 7 == 0 or n % 11 == 0 or n % 13 == 0:
-    n -= 2
+import random
+n = random.Random(bits).getrandbits(bits) | (1 << (bits - 1)) | 1     # generic: not of the form 2^k -/+ 1
 eng = pyecm.Engine(n, digitbits=52)
 print("N = 2^%d-ish, NL = %d, B1 = %d, %s" % (bits, eng.cfg.dev_limbs, b1, eng.device_name()))
 for batch in (1024, 4096, 16384, 32768, 49152, 65536, 98304, 131072):

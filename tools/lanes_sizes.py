@@ -11,9 +11,8 @@ batch = int(sys.argv[2]) if len(sys.argv) > 2 else 131072
 nls = [int(x) for x in sys.argv[3].split(',')] if len(sys.argv) > 3 else [8, 10, 12, 14, 15, 17, 19, 21, 23, 26, 28, 30, 32, 34, 37]
 for nl in nls:
     bits = 28 * nl - 5
-    n = (1 << bits) - 1
-    while any(n % p == 0 for p in (3, 5, 7, 11, 13)):
-        n -= 2
+    import random
+    n = random.Random(bits).getrandbits(bits) | (1 << (bits - 1)) | 1     # generic: not of the form 2^k -/+ 1
     eng = pyecm.Engine(n, digitbits=52)
     assert eng.cfg.dev_limbs == nl, (eng.cfg.dev_limbs, nl)
     eng.build_curves(list(range(1000, 1000 + batch)))

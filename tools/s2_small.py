@@ -4,9 +4,8 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import pyecm
 b2 = int(sys.argv[1]) if len(sys.argv) > 1 else 100000000
 batches = [int(x) for x in sys.argv[2:]] or [4096, 32768, 131072]
-n = (1 << 415) - 1
-while any(n % p == 0 for p in (3, 5, 7, 11, 13)):
-    n -= 2
+import random
+n = random.Random(415).getrandbits(415) | (1 << 414) | 1               # generic: not of the form 2^k -/+ 1
 eng = pyecm.Engine(n, digitbits=52)
 for b in batches:
     eng.build_curves(list(range(1000, 1000 + b)))
