@@ -247,7 +247,7 @@ extern "C" int gecm_dev_auto_lanes(gecm_dev *d)
      * quads, the limbs of a residue spread over the quad, csrc/gecm_quad.hpp) — 1.5x the two-lane layout at 15
      * limbs, 2.2-2.4x at 30-37 limbs, up to 32 curves per CU; from 19 limbs up still 1.2-1.4x at 64 curves
      * per CU (tools/quad_check.py).  Generic moduli only. */
-    if (!d->fform && d->dModQ && d->stride <= (size_t)d->cus * (d->nl >= 19 ? 64 : 32)) return 8;
+    if (!d->fform && d->dModQ && d->stride && d->stride <= (size_t)d->cus * (d->nl >= 19 ? 64 : 32)) return 8;
     if (d->nl >= 26) return 2;
     const size_t full = (size_t)d->cus * 4 * 128;
     const size_t r = d->stride % full;

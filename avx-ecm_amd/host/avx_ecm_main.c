@@ -162,9 +162,10 @@ int main(int argc, char **argv)
     if (inf.ref_special_reduction) {
         /* main.c:644-670 prints "Using special Mersenne mod for factor of: 2^k-1" here */
         int fk = 0, fl = 0;
-        if (gecm_get_special_form(jobs[0].ctx, &fk, &fl) == 1)
-            printf("Using REDC modulo 2^%d%c1 (%d limbs, special reduction) for stage 1 of this factor of 2^%d%c1; "
-                   "residues are reduced modulo N\n", abs(fk), fk > 0 ? '-' : '+', fl, abs(fk), fk > 0 ? '-' : '+');
+        if (gecm_get_special_form(jobs[0].ctx, &fk, &fl) >= 1)
+            printf("REDC modulo 2^%d%c1 (%d limbs, special reduction) serves stage 1 of this factor of 2^%d%c1 when the "
+                   "batch is large enough for it; residues are reduced modulo N\n", abs(fk), fk > 0 ? '-' : '+', fl,
+                   abs(fk), fk > 0 ? '-' : '+');
         else
             printf("Input divides 2^%d %c %d: running REDC on the %d-bit cofactor (residues = the reference's modulo N)\n",
                    inf.k, inf.form > 0 ? '-' : '+', inf.form, inf.nbits);

@@ -218,10 +218,14 @@ class Engine:
         _chk(lib.gecm_set_special_form(self._h, 1 if on else 0), "gecm_set_special_form")
 
     def special_form(self):
-        """(in use, k, limbs)"""
+        """(enabled, k, limbs)"""
         k, l = c_int(0), c_int(0)
         r = _chk(lib.gecm_get_special_form(self._h, ctypes.byref(k), ctypes.byref(l)), "gecm_get_special_form")
         return bool(r), k.value, l.value
+
+    def special_form_used(self):
+        """True if the last stage-1 launch ran with the special multiply"""
+        return _chk(lib.gecm_get_special_form(self._h, None, None), "gecm_get_special_form") == 2
 
     def lanes_per_curve(self):
         """what the last stage-1 launch used"""

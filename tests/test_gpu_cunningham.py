@@ -56,6 +56,7 @@ def test_special_reduction_case_residues_equal_the_references_modulo_n():
         eng.build_curves(sig)
         eng.set_lanes_per_curve(lanes)
         eng.stage1(c["B1"])
+        assert eng.special_form_used()                     # N | 2^251 - 1: the F-form kernel ran
         mine = eng.save_lines()
         eng.close()
         for k, (l, r) in enumerate(zip(mine, c["save_lines"])):
@@ -76,7 +77,7 @@ def test_driver_on_a_mersenne_cofactor_names_the_path_and_writes_residues_modulo
         assert p.returncode == 0, p.stdout + p.stderr
         save = open(os.path.join(d, "save_b1.txt")).read().splitlines()
     assert "removing algebraic C1 factor 0" in p.stdout                       # what the reference prints here
-    assert "Using REDC modulo 2^251-1 (10 limbs, special reduction) for stage 1" in p.stdout
+    assert "REDC modulo 2^251-1 (10 limbs, special reduction) serves stage 1" in p.stdout
     assert len(save) == 8
     for k, (l, r) in enumerate(zip(save, c["save_lines"])):
         assert _field(l, "N") == n and _field(l, "X") < n and _field(l, "Z") < n

@@ -7,14 +7,15 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _lines(n, sig, b1, special):
+def _lines(n, sig, b1, special, lanes=2):
     import pyecm
     eng = pyecm.Engine(n, digitbits=52)
     avail = eng.special_form()
     eng.set_special_form(special)
+    eng.set_lanes_per_curve(lanes)          # explicit: left to itself a batch this small takes the eight-lane generic kernel
     eng.build_curves(sig)
     eng.stage1(b1)
-    used = eng.special_form()[0] and special
+    used = eng.special_form_used()
     lines = eng.save_lines()
     facs = [eng.stage1_factor(k) for k in range(len(sig))]
     eng.close()
@@ -59,9 +60,11 @@ def test_special_form_survives_a_second_stage1_and_stage2():
     for special in (True, False):
         eng = pyecm.Engine(n)
         eng.set_special_form(special)
+        eng.set_lanes_per_curve(1)
         eng.build_curves(sig)
         eng.stage1(500)
         eng.stage1(500)
+        assert eng.special_form_used() == special
         lines = eng.save_lines()
         eng.stage2(20000)
         out[special] = (lines, eng.download_acc())
@@ -84,9 +87,10 @@ def test_special_form_through_upload_points(k):
         eng = pyecm.Engine(n)
         R = 1 << eng.cfg.maxbits
         eng.set_special_form(special)
+        eng.set_lanes_per_curve(2)
         eng.upload_points([x * R % n for x in xs], [R % n] * 40, [s * R % n for s in ss])
         eng.stage1(700)
-        assert eng.special_form()[0] == special
+        assert eng.special_form_used() == special
         out[special] = (eng.download_points(), eng.download_points_plain())
         eng.close()
     assert out[True] == out[False]
@@ -125,6 +129,25 @@ def test_special_form_at_both_ends_of_every_limb_count(nl, k):
             eng.set_lanes_per_curve(lanes)
             eng.build_curves(sig)
             eng.stage1(1200)
+            assert eng.special_form_used() == special
             out.append(eng.save_lines())
     eng.close()
     assert out[0] == out[1] == out[2] == out[3]
+
+
+def test_small_batches_prefer_the_eight_lane_generic_kernel():
+    """left to itself (lanes = 0) a small batch of a 2^k - 1 cofactor runs the eight-lane generic kernel, a large
+    one the special multiply; same save lines either way"""
+    import pyecm
+    n = (1 << 401) - 1
+    eng = pyecm.Engine(n)
+    assert eng.special_form() == (True, 401, 15)
+    eng.build_curves(list(range(7000, 7032)))
+    eng.stage1(400)
+    assert eng.lanes_per_curve() == 8 and not eng.special_form_used()
+    small = eng.save_lines()
+    eng.build_curves(list(range(7000, 7000 + 20000)))
+    eng.stage1(400)
+    assert eng.lanes_per_curve() == 2 and eng.special_form_used()
+    assert eng.save_lines()[:32] == small
+    eng.close()
