@@ -58,3 +58,23 @@ def test_cli_rounds_curves_up_to_a_multiple_of_8():
     c = S1["K1N_two_full_batches_b1_500"]          # N without small factors, sigma 100.., 16 lines in the fixture
     out, save, res = _run([c["N"], 10, c["B1"], 1, c["B2"], c["sigma0"]])
     assert save.splitlines() == c["save_lines"] and len(c["save_lines"]) == 16
+
+
+def test_cli_more_curves_than_one_pass():
+    """more curves than one pass holds (131072 per GPU): the driver runs a second pass and the sigmas continue
+    (main.c:761, ecm.c:1187); N without small factors so that no factor stops the run after pass one"""
+    import pyecm
+    c = S1["K1N_two_full_batches_b1_500"]
+    n = int(c["save_lines"][0].split("N=0x")[1].split(";")[0], 16)
+    curves, b1, sigma0 = 131072 + 16, 30, 500000
+    out, save, res = _run([c["N"], curves, b1, 1, b1, sigma0])
+    lines = save.splitlines()
+    assert len(lines) == curves and "Commencing curves 131072-131087 of 131088" in out
+    sig = [int(l.split("SIGMA=")[1].split(";")[0]) for l in lines]
+    assert sig == list(range(sigma0, sigma0 + curves))
+    eng = pyecm.Engine(n)
+    pick = [0, 1, 131071, 131072, 131087]
+    eng.build_curves([sigma0 + k for k in pick])
+    eng.stage1(b1)
+    assert [l.rstrip("\n") for l in eng.save_lines()] == [lines[k] for k in pick]
+    eng.close()
