@@ -210,7 +210,8 @@ class Engine:
         _chk(lib.gecm_sync(self._h), "gecm_sync")
 
     def set_lanes_per_curve(self, lanes):
-        """0 = chosen per launch from the batch size, 1 = curve per lane, 2 = X and Z on adjacent lanes"""
+        """0 = chosen per launch from the batch size, 1 = curve per lane, 2 = X and Z on adjacent lanes,
+        8 = X and Z on two quads of lanes with the limbs of each residue spread over the quad"""
         _chk(lib.gecm_set_lanes_per_curve(self._h, lanes), "gecm_set_lanes_per_curve")
 
     def set_special_form(self, on):
