@@ -276,7 +276,7 @@ def main():
             line["stage2"] = stage2
         if special:
             line["special_form"] = special
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only: the other ranks would wait at the barrier
             line["cpu_baseline"] = cpu_baseline(n, a.b1)
         print(json.dumps(line), flush=True)
     eng.close()
