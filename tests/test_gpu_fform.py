@@ -151,3 +151,28 @@ def test_small_batches_prefer_the_eight_lane_generic_kernel():
     assert eng.lanes_per_curve() == 2 and eng.special_form_used()
     assert eng.save_lines()[:32] == small
     eng.close()
+
+
+def test_results_can_be_read_without_an_explicit_sync():
+    """gecm_stage1 is asynchronous; every consumer of its result (save lines, factor scan, stage 2) waits for it
+    and, for a special-form launch, first brings X and Z back modulo N"""
+    import pyecm
+    n = (1 << 401) - 1
+    sig = list(range(9000, 9040))
+    ref = None
+    for special, consumer in ((False, "lines"), (True, "lines"), (True, "scan"), (True, "stage2")):
+        eng = pyecm.Engine(n)
+        eng.set_special_form(special)
+        eng.set_lanes_per_curve(2)
+        eng.build_curves(sig)
+        eng.stage1(2000, sync=False)
+        if consumer == "scan":
+            eng.scan_factors(1)
+        elif consumer == "stage2":
+            eng.stage2_init()
+        lines = eng.save_lines()
+        assert eng.special_form_used() == special
+        eng.close()
+        if ref is None:
+            ref = lines
+        assert lines == ref
