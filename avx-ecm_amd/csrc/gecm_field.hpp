@@ -5,6 +5,8 @@
 //   vecsubmod52 (:4684-4723), vec_simul_addsub52 (:4877-4968) and the 32-bit twins in vecarith.c.
 //
 // Design: ONE CURVE PER LANE, 64 curves per wavefront, no cross-lane traffic.
+// (Batches too small to fill the chip use the same arithmetic with a curve's X and Z on two adjacent lanes —
+// gecm_curve.hpp, run_tape_pair — or a row-wise multiply with a residue spread over four lanes — gecm_quad.hpp.)
 // A residue is NL limbs of 28 bits held in 32-bit VGPRs; the modulus N, the subtraction bias K'
 // and rho are wave-uniform (kernel arguments -> SGPRs).  The multiply is product-scanning
 // (column-wise) Montgomery with ONE 64-bit column accumulator fed by v_mad_u64_u32:
