@@ -1,19 +1,35 @@
 #!/usr/bin/env python3
 """bench.py — stage-1 curves/sec at B1=1e6 on 416-bit-class N (BASELINE.json metric).
 
-One process per GPU (torch.distributed over RCCL when --gpus > 1).  A "step" is one pass of the
-hot path (ecm_stage1: PRAC ladder over all prime powers < B1) over one batch of curves already
-resident in HBM; K steps run back to back on the resident points (the output of a stage 1 is a
-valid input point of the next).  value = curves processed by all ranks / max-over-ranks time.
+Workload of the headline line = BASELINE.json configs[1]: 4096 curves per GPU, 415-bit random odd N,
+B1 = 1e6, reference limb format 52-bit, the library's own choice of lanes per curve.  A "step" is one
+pass of the hot path (ecm_stage1: the PRAC ladder over all prime powers < B1, ecm.c:1806-1854) over that
+batch, already resident in HBM, plus the device factor scan and the ONE collective of the path (max-reduce
+of the found record).  K steps run back to back on the resident points (the output of a stage 1 is a valid
+input point of the next).  value = curves processed by all ranks / max-over-ranks time — the figure the
+reference prints as "Stage 1 took" (ecm.c:1315-1317), inverted.
 
-Extra objects on the JSON line:
-  roofline      VALU-issue roofline of the dominant kernel (k_stage1): achieved integer
-                multiply-adds (v_mad_u64_u32, the instruction the multiply is built from) per second
-                against the gfx950 issue peak; plus the same in SURVEY.md §8d units (52-bit limb
-                products).  Kernel time from HIP events on the kernel's own stream.
-  cpu_baseline  the reference's own AVX-512 binary (oracle/_ref, built from /root/reference in the
-                build container) timed on this box's host cores on a bounded sample; falls back to
-                the scalar-C port (oracle/) if the binary is absent or cannot run here.
+Launch:  python bench.py --gpus N --steps K --warmup W
+  * N > 1 without WORLD_SIZE in the environment: this process touches no GPU; it starts N ranks through
+    torch.distributed.run (one process per GPU, RCCL) as a child process and relays rank 0's line.
+  * under torch.distributed.run (RANK/LOCAL_RANK/WORLD_SIZE set): --gpus must equal WORLD_SIZE.
+  * every rank works on its own 4096 curves (weak scaling: N = 8 is BASELINE configs[3]).
+
+Time budget (--budget-s, default 450 s): the step count is derived from the first warm-up step so that
+warm-up + timed steps + the CPU baseline stay inside it ("steps_requested" records what was asked for);
+the extras run only while budget is left.  Rank 0 prints ONE JSON line on stdout.
+
+Extra objects on the line:
+  roofline      VALU-issue roofline of the dominant kernel: achieved integer multiply-adds
+                (v_mad_u64_u32, the instruction the multiply is built from) per second against the gfx950
+                issue peak; the same in SURVEY.md §8d units (52-bit limb products).  Kernel time from HIP
+                events on the kernel's own stream.
+  cpu_baseline  the reference's own AVX-512 binary (oracle/_ref, built from /root/reference in the build
+                container) timed on this box's host cores on a bounded sample; the scalar-C port
+                (oracle/) if the binary is absent or cannot run here.
+  saturated     131072 curves in one launch (one curve per lane, 2 wavefronts per SIMD)
+  config2 / config4   BASELINE configs[2] (4096 x 831-bit, B1=1e6) and configs[4] (1023-bit, 32-bit
+                reference limbs, B1=1e5), one warm-up and one step each
 """
 import argparse
 import ctypes
@@ -21,6 +37,7 @@ import json
 import os
 import random
 import re
+import socket
 import subprocess
 import sys
 import tempfile
@@ -29,12 +46,14 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "avx-ecm_amd"))
 
-# point-op counts per curve at B1=1e6 (reference counters ecm.c:441, 455)
 PEAK_MAD_PER_S = 256 * 4 * 16 * 2.4e9      # CUs x SIMDs x lanes/clk (v_mad_u64_u32: 4 clk per wave64) x Hz
 PEAK_FMA64_PER_S = 256 * 4 * 16 * 2.4e9    # v_fma_f64 issues at the same rate (78.6 TFLOP/s datasheet)
+KERNEL_NAMES = {1: "k_stage1<%d>", 2: "k_stage1_pair<%d>", 8: "k_stage1_quad<%d>", 32: "k_stage1_row<%d>"}
 
 
 def work_per_curve(ptadds, ptdups, nl, n52):
+    """(mul, sqr, 28-bit multiply-adds, 52-bit limb products) of one curve's stage 1: point-op counters of
+    the reference (ecm.c:441, 455) x 4 mul + 2 sqr per add, 3 mul + 2 sqr per doubling; SURVEY.md §8d"""
     mul = 4 * ptadds + 3 * ptdups
     sqr = 2 * ptadds + 2 * ptdups
     mads = mul * (2 * nl * nl + nl) + sqr * (nl * (nl + 1) // 2 + nl * nl + nl)
@@ -60,35 +79,34 @@ def host_cores():
     return max(1, min(n, 64))
 
 
-def cpu_baseline(n, b1, budget_s=25.0):
-    """reference AVX-512 binary on the host cores; bounded sample."""
+def cpu_baseline(n, b1, budget_s=30.0):
+    """reference AVX-512 binary on the host cores; bounded sample (8 curves on 1 thread, then 8 per core)."""
     exe = os.path.join(ROOT, "oracle", "_ref", "avx-ecm-52")
     ncores = host_cores()
     out = None
+    t_start = time.perf_counter()
     if os.path.exists(exe):
         try:
-            # 1 thread x 8 curves first (~5 s at B1=1e6 on a 2 GHz core)
-            def run(threads):
+            def run(threads, timeout):
                 with tempfile.TemporaryDirectory() as d:
                     p = subprocess.run([exe, str(n), str(8 * threads), str(b1), str(threads), str(b1), "1000"],
-                                       cwd=d, capture_output=True, text=True, timeout=600)
+                                       cwd=d, capture_output=True, text=True, timeout=timeout)
                 m = re.search(r"Stage 1 took ([0-9.]+) seconds", p.stdout)
                 if p.returncode != 0 or not m:
                     raise RuntimeError("reference binary failed rc=%d" % p.returncode)
                 return float(m.group(1))
-            t1 = run(1)
-            res = {"value": 8 / t1, "unit": "curves/s", "cores": 1, "kind": "reference",
+            t1 = run(1, max(20.0, 3 * budget_s))
+            out = {"value": 8 / t1, "unit": "curves/s", "cores": 1, "kind": "reference",
                    "sample": "oracle/_ref/avx-ecm-52 N 8 %d 1 %d 1000: 8 curves, 1 thread, %.2f s stage 1" % (b1, b1, t1)}
-            if t1 * 1.5 < budget_s and ncores > 1:
-                thr = ncores
-                tn = run(thr)
-                res = {"value": 8 * thr / tn, "unit": "curves/s", "cores": thr, "kind": "reference",
+            left = budget_s - (time.perf_counter() - t_start)
+            if ncores > 1 and t1 * 2.0 < left:
+                tn = run(ncores, max(20.0, 4 * t1))
+                out = {"value": 8 * ncores / tn, "unit": "curves/s", "cores": ncores, "kind": "reference",
                        "sample": "oracle/_ref/avx-ecm-52 N %d %d %d %d 1000: %d curves on %d threads, %.2f s stage 1; "
-                                 "1 thread: %.3f curves/s" % (8 * thr, b1, thr, b1, 8 * thr, thr, tn, 8 / t1)}
-            out = res
-        except Exception as e:  # SIGILL on a host without AVX-512, missing libgmp, ...
-            out = None
-            note = "reference binary unusable here: %s" % e
+                                 "1 thread: %.3f curves/s" % (8 * ncores, b1, ncores, b1, 8 * ncores, ncores, tn, 8 / t1)}
+        except Exception as e:  # SIGILL on a host without AVX-512, missing libgmp, time-out, ...
+            if out is None:
+                sys.stderr.write("bench: reference binary unusable here (%s); timing the scalar port\n" % e)
     if out is None:
         so = os.path.join(ROOT, "oracle", "libecm_oracle.so")
         L = ctypes.CDLL(so)
@@ -103,31 +121,121 @@ def cpu_baseline(n, b1, budget_s=25.0):
     return out
 
 
+def plan_steps(steps, warmup, t_probe, avail_s):
+    """(further warm-up steps, timed steps) after the probe step, which is warm-up step 1: what was asked
+    for if it fits into avail_s at t_probe seconds per step, else at most one more warm-up step and as many
+    timed steps as fit (at least 1)"""
+    steps = max(1, steps)
+    more_warm = max(0, warmup - 1)
+    afford = int(avail_s / max(t_probe, 1e-6))
+    if more_warm + steps > afford:
+        more_warm = min(more_warm, 1)
+        steps = max(1, min(steps, afford - more_warm))
+    return more_warm, steps
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(a, argv):
+    """--gpus N > 1 outside a torch.distributed launch: start the N ranks as a child process.  Nothing in this
+    process has touched the GPU (no torch, no libgecm import), so the child launcher is an ordinary spawn."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run(cmd, env=env)
+    return p.returncode
+
+
+class NoEngine:
+    """--no-engine: rehearsal of the launcher and of the collective control flow on a box without a GPU
+    (CPU tests).  Computes nothing; the line it produces is marked "rehearsal" and carries no roofline."""
+
+    class _Cfg:
+        dev_limbs, nwords, maxbits = 15, 8, 416
+
+    class _St:
+        ptadds, ptdups = 1980817, 217929
+
+    cfg = _Cfg()
+
+    def build_curves(self, sig):
+        self.batch = len(sig)
+
+    def set_lanes_per_curve(self, lanes):
+        pass
+
+    def stage1(self, b1, sync=True):
+        time.sleep(0.01)
+
+    def last_kernel_ms(self):
+        return 10.0
+
+    def scan_factors(self, stage=1):
+        return 0, None
+
+    def stage1_stats(self):
+        return self._St()
+
+    def lanes_per_curve(self):
+        return 0
+
+    def close(self):
+        pass
+
+
+def timed_pass(eng, b1, warm):
+    """one optional warm-up and one stage-1 pass on the resident batch: (wall s, kernel ms)"""
+    if warm:
+        eng.stage1(b1, sync=True)
+    t = time.perf_counter()
+    eng.stage1(b1, sync=True)
+    return time.perf_counter() - t, eng.last_kernel_ms()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--curves", type=int, default=131072, help="curves per GPU per step")
+    ap.add_argument("--curves", type=int, default=4096, help="curves per GPU per step (BASELINE configs[1]: 4096)")
     ap.add_argument("--bits", type=int, default=415)
     ap.add_argument("--b1", type=int, default=1000000)
+    ap.add_argument("--budget-s", type=float, default=450.0, help="wall-clock budget of the whole run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-small-batch", action="store_true")
-    ap.add_argument("--lanes", type=int, default=0, help="lanes per curve in stage 1: 0 = library's choice, 1, 2")
-    ap.add_argument("--no-special-form", action="store_true", help="skip the extra 2^401-1 measurement")
+    ap.add_argument("--no-extras", action="store_true", help="skip saturated / config2 / config4 / special_form")
+    ap.add_argument("--lanes", type=int, default=0, help="lanes per curve in stage 1: 0 = library's choice, 1, 2, 8, 32")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; "
-                    "gloo only to rehearse the multi-rank control flow on fewer GPUs than ranks)")
-    ap.add_argument("--b2", type=int, default=0, help="also time one stage-2 pass to this B2 (reported separately)")
+                    "gloo only to rehearse the multi-rank control flow)")
+    ap.add_argument("--b2", type=int, default=0, help="also time one stage-2 pass to this B2 on every rank "
+                    "(BASELINE configs[3]: 100000000); reported separately as \"stage2\"")
+    ap.add_argument("--no-engine", action="store_true", help="rehearsal without a GPU: launcher + collectives only")
     a = ap.parse_args()
+    t_begin = time.perf_counter()
 
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(launch_ranks(a, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d: launch one rank per GPU" % (a.gpus, world))
+
     import torch
     dist = None
-    import pyecm
-    ndev = max(1, pyecm.device_count())
-    devno = local_rank % ndev
+    if a.no_engine:
+        pyecm, devno = None, 0
+    else:
+        import pyecm
+        ndev = max(1, pyecm.device_count())
+        devno = local_rank % ndev
+    on_gpu = not a.no_engine and (world == 1 or a.backend == "nccl")
     if world > 1:
         import torch.distributed as dist
         if a.backend == "nccl":
@@ -135,105 +243,94 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", devno))
         else:
             dist.init_process_group(backend=a.backend)
+    dev = "cuda:%d" % devno if on_gpu else "cpu"
 
-    from pyecm import shard
+    if a.no_engine:
+        sys.path.insert(0, os.path.join(ROOT, "avx-ecm_amd", "pyecm"))
+        import shard
+    else:
+        from pyecm import shard
     n = random.Random(a.bits).getrandbits(a.bits) | (1 << (a.bits - 1)) | 1
-    eng = pyecm.Engine(n, digitbits=52, device=devno)
+    eng = NoEngine() if a.no_engine else pyecm.Engine(n, digitbits=52, device=devno)
     # host-side split of the curve batch (pyecm/shard.py): rank g owns the contiguous global curve
     # indices [g*C, (g+1)*C), sigma = 1000 + index
     total = a.curves * world
     lo, hi = shard.shard_bounds(total, rank, world)
     eng.build_curves(shard.shard_sigmas(1000, total, rank, world))
-    dev = "cuda:%d" % devno if (world == 1 or a.backend == "nccl") else "cpu"
+    eng.set_lanes_per_curve(a.lanes)
 
     def barrier():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
+
+    def allmax(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
     kernel_ms = []
-
     found_log = []
-
-    eng.set_lanes_per_curve(a.lanes)
 
     def step():
         eng.stage1(a.b1, sync=True)
         kernel_ms.append(eng.last_kernel_ms())
         # factor scan of the whole batch on the device (check_factor, ecm.c:2542-2557), then the ONE
-        # collective of the path: max-reduce of the found record (lowest global curve with a factor)
+        # collective of the path: max-reduce of the found record (lowest global curve with a factor);
+        # it replaces the reference's scan + break, ecm.c:1323-1370
         nf, first = eng.scan_factors(1)
         g = shard.allreduce_found(dist, None if first is None else lo + first, total, device=dev)
         found_log.append((nf, g))
 
-    for _ in range(a.warmup):
+    # ---- step count from the budget: one probe step (the first warm-up step, or an extra one) ----
+    t0 = time.perf_counter()
+    step()                                   # warm-up step 1 (run even with --warmup 0: it is the probe)
+    t_probe = allmax(time.perf_counter() - t0)
+    cpu_reserve = 0.0 if (a.no_cpu_baseline or world > 1) else 40.0
+    avail = a.budget_s - (time.perf_counter() - t_begin) - cpu_reserve - 10.0
+    # identical on every rank: t_probe is the max over ranks, and rank 0's clock decides
+    avail = allmax(avail if rank == 0 else -1e30)
+    more_warm, steps = plan_steps(a.steps, a.warmup, t_probe, avail)
+    warmup = 1 + more_warm
+    for _ in range(more_warm):
         step()
     kernel_ms.clear()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for _ in range(steps):
         step()
     barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = allmax(time.perf_counter() - t0)
 
     st = eng.stage1_stats()
     cfg = eng.cfg
     lanes = eng.lanes_per_curve()
-    kname = ("k_stage1<%d>" if lanes == 1 else "k_stage1_pair<%d>") % cfg.dev_limbs
+    kname = KERNEL_NAMES.get(lanes, "k_stage1_l%d<%%d>" % lanes) % cfg.dev_limbs
+
     stage2 = None
-    if a.b2 > a.b1:
-        # not part of the metric: one pass of the stage-2 continuation on the resident batch
+    if a.b2 > a.b1 and not a.no_engine:
+        # not part of the metric: one pass of the stage-2 continuation on every rank's resident batch
+        barrier()
         t2 = time.perf_counter()
         eng.stage2(a.b2)
-        nf2, _ = eng.scan_factors(2)
-        t2 = time.perf_counter() - t2
+        nf2, first2 = eng.scan_factors(2)
+        shard.allreduce_found(dist, None if first2 is None else lo + first2, total, device=dev)
+        barrier()
+        t2 = allmax(time.perf_counter() - t2)
         s2 = eng.stage2_stats()
-        stage2 = {"B2": a.b2, "seconds": t2, "curves_per_s": a.curves / t2, "D": s2.D, "U": s2.U,
+        stage2 = {"B2": a.b2, "seconds": t2, "curves_per_s": total / t2, "D": s2.D, "U": s2.U,
                   "ptadds": s2.ptadds, "inversions": s2.numinv, "pair_muls": s2.paired,
-                  "curves_with_factor": nf2}
-    small = None
-    if world == 1 and a.curves != 4096 and not a.no_small_batch:
-        # BASELINE.json configs[1] names a 4096-curve batch: with one curve per lane that is 64
-        # wavefronts for 1024 SIMDs, so the library spreads each curve over eight lanes (512 wavefronts:
-        # X and Z on two quads, the limbs of a residue over the lanes of its quad).  Measured separately
-        # (one pass) and reported next to `value`.
-        eng.build_curves(list(range(1000, 1000 + 4096)))
-        eng.set_lanes_per_curve(0)
-        t1 = time.perf_counter()
-        eng.stage1(a.b1, sync=True)
-        t1 = time.perf_counter() - t1
-        small = {"curves": 4096, "value": 4096 / t1, "unit": "curves/s", "ms_per_step": t1 * 1e3,
-                 "kernel_ms": eng.last_kernel_ms(), "lanes_per_curve": eng.lanes_per_curve()}
-    special = None
-    if world == 1 and not a.no_special_form and not a.no_small_batch:
-        # not part of the metric: a Mersenne-form modulus (the reference's isMersenne inputs) through the
-        # generic REDC kernel and through the 2^k - 1 multiply, same batch, B1 = 1e5 (parity of the two paths
-        # is tests/test_gpu_fform.py's job; this is the timing)
-        try:
-            e2 = pyecm.Engine((1 << 401) - 1, digitbits=52, device=devno)
-            ms = {}
-            for on in (False, True):
-                e2.set_special_form(on)
-                e2.set_lanes_per_curve(1)
-                e2.build_curves(list(range(1000, 1000 + a.curves)))
-                e2.stage1(100000, sync=True)
-                ms[on] = e2.last_kernel_ms()
-            special = {"N": "2^401-1", "curves": a.curves, "B1": 100000, "generic_redc_kernel_ms": ms[False],
-                       "special_form_kernel_ms": ms[True], "speedup": ms[False] / ms[True]}
-            e2.close()
-        except Exception as ex:                 # the extra must never cost the headline line
-            special = {"error": str(ex)}
+                  "curves_with_factor_rank0": nf2}
+
+    line = None
     if rank == 0:
-        total_curves = a.curves * world * a.steps
-        value = total_curves / dt
+        value = a.curves * world * steps / dt
         mul, sqr, mads, w52 = work_per_curve(st.ptadds, st.ptdups, cfg.dev_limbs, cfg.nwords)
         kms = sum(kernel_ms) / len(kernel_ms)
-        mads_per_launch = mads * a.curves
-        achieved = mads_per_launch / (kms * 1e-3)
+        achieved = mads * a.curves / (kms * 1e-3)
         traffic = None
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
@@ -248,6 +345,8 @@ def main():
             "traffic_note": "HBM bytes per launch from rocprofv3 PMC passes of this command (profiles/), FETCH_SIZE x2 "
                             "per the gfx950 correction; null if no matching profile is committed",
             "kernel_ms_avg": kms, "mads_per_curve": mads,
+            "mads_note": "algorithmic: product-scanning multiply 2n^2+n, square n(n+1)/2+n^2+n on n=%d limbs of 28 bits; "
+                         "a layout that spends more instructions than that scores lower, not higher" % cfg.dev_limbs,
             "survey_units": {"limb_products_52bit_per_curve": w52,
                              "achieved_T52/s": w52 * a.curves / (kms * 1e-3) / 1e12,
                              "peak_T52/s_fp64_fma_pair": PEAK_FMA64_PER_S / 2 / 1e12,
@@ -256,28 +355,97 @@ def main():
         }
         line = {
             "metric": "stage-1 curves/sec at B1=%d, %d-bit N" % (a.b1, cfg.maxbits), "value": value,
-            "unit": "curves/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "unit": "curves/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "steps_requested": a.steps, "warmup_requested": a.warmup, "probe_step_s": t_probe,
+            "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32 (28-bit limbs, 64-bit accumulate)", "data": "synthetic",
-            "config": {"workload": "%d curves per GPU per step (= %d sub-batches of the 4096 curves of BASELINE "
-                                   "configs[1], in one launch: one curve per lane needs 131072 curves to put 2 "
-                                   "wavefronts on each of the 1024 SIMDs), %d-bit random odd N (seed %d), B1=%d, "
-                                   "sigma=1000.., stage 1 + device factor scan; reference limb format 52-bit NWORDS=%d"
-                                   % (a.curves, a.curves // 4096, a.bits, a.bits, a.b1, cfg.nwords),
+            "config": {"workload": "BASELINE configs[1]: %d curves per GPU per step, %d-bit random odd N (seed %d), B1=%d, "
+                                   "sigma=1000.., stage 1 + device factor scan + found-record all-reduce; reference limb "
+                                   "format 52-bit NWORDS=%d" % (a.curves, a.bits, a.bits, a.b1, cfg.nwords),
                        "curves_per_gpu": a.curves, "bits": a.bits, "B1": a.b1, "lanes_per_curve": lanes,
                        "curves_with_factor_last_step": found_log[-1][0],
                        "parallelism": "curve batch split across %d GPU(s) on the host, no data-path collective, "
-                                      "1 all-reduce (RCCL) of the found record per step" % world},
+                                      "1 all-reduce (%s) of the found record per step"
+                                      % (world, "RCCL" if a.backend == "nccl" else a.backend)},
             "roofline": roof,
         }
-        if small:
-            line["batch_4096"] = small
+        if a.no_engine:
+            line["rehearsal"] = "no engine: launcher and collectives only, value is meaningless"
+            line.pop("roofline")
         if stage2:
             line["stage2"] = stage2
-        if special:
-            line["special_form"] = special
-        if not a.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only: the other ranks would wait at the barrier
-            line["cpu_baseline"] = cpu_baseline(n, a.b1)
+        sys.stderr.write("bench: headline %.1f curves/s (%d steps, %.1f ms/step)\n" % (value, steps, dt / steps * 1e3))
+
+    def left():
+        return a.budget_s - (time.perf_counter() - t_begin)
+
+    if rank == 0 and world == 1 and not a.no_engine:
+        # ---- rank 0 at N = 1 only: the other ranks would wait at the barrier ----
+        if not a.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline(n, a.b1, budget_s=min(30.0, max(8.0, left() - 15.0)))
+            except Exception as ex:
+                line["cpu_baseline"] = {"error": str(ex)}
+        extras = [] if a.no_extras else ["config2", "config4", "saturated", "special_form"]
+        per_curve_s = dt / steps / a.curves          # of the headline layout; the estimates below are upper bounds
+        for name in extras:
+            try:
+                if name == "config2":            # BASELINE configs[2]: 4096 x 832-bit class
+                    if left() < 2 * 4.5 * t_probe + 20:
+                        raise TimeoutError("budget")
+                    n2 = random.Random(831).getrandbits(831) | (1 << 830) | 1
+                    e2 = pyecm.Engine(n2, digitbits=52, device=devno)
+                    e2.build_curves(list(range(1000, 1000 + 4096)))
+                    w, k = timed_pass(e2, a.b1, True)
+                    s2 = e2.stage1_stats()
+                    m2 = work_per_curve(s2.ptadds, s2.ptdups, e2.cfg.dev_limbs, e2.cfg.nwords)[2]
+                    line[name] = {"workload": "4096 curves, 831-bit random odd N (seed 831), B1=%d" % a.b1,
+                                  "value": 4096 / w, "unit": "curves/s", "kernel_ms": k, "lanes_per_curve": e2.lanes_per_curve(),
+                                  "dev_limbs": e2.cfg.dev_limbs, "valu_frac": m2 * 4096 / (k * 1e-3) / PEAK_MAD_PER_S}
+                    e2.close()
+                elif name == "config4":          # BASELINE configs[4]: DIGITBITS=32 boundary, 1024-bit class, B1=1e5
+                    if left() < 2 * 1.0 * t_probe + 15:
+                        raise TimeoutError("budget")
+                    n4 = random.Random(1023).getrandbits(1023) | (1 << 1022) | 1
+                    e4 = pyecm.Engine(n4, digitbits=32, device=devno)
+                    e4.build_curves(list(range(1000, 1000 + 4096)))
+                    w, k = timed_pass(e4, 100000, True)
+                    s4 = e4.stage1_stats()
+                    m4 = work_per_curve(s4.ptadds, s4.ptdups, e4.cfg.dev_limbs, e4.cfg.nwords)[2]
+                    line[name] = {"workload": "4096 curves, 1023-bit random odd N (seed 1023), 32-bit reference limbs, B1=100000",
+                                  "value": 4096 / w, "unit": "curves/s", "kernel_ms": k, "lanes_per_curve": e4.lanes_per_curve(),
+                                  "dev_limbs": e4.cfg.dev_limbs, "valu_frac": m4 * 4096 / (k * 1e-3) / PEAK_MAD_PER_S}
+                    e4.close()
+                elif name == "saturated":        # one curve per lane, 2 wavefronts on every SIMD
+                    if left() < 2 * 27.0 + 15:
+                        raise TimeoutError("budget")
+                    eng.build_curves(list(range(1000, 1000 + 131072)))
+                    eng.set_lanes_per_curve(0)
+                    w, k = timed_pass(eng, a.b1, True)
+                    line[name] = {"workload": "131072 curves in one launch, %d-bit N, B1=%d" % (a.bits, a.b1),
+                                  "value": 131072 / w, "unit": "curves/s", "kernel_ms": k, "lanes_per_curve": eng.lanes_per_curve(),
+                                  "valu_frac": work_per_curve(st.ptadds, st.ptdups, cfg.dev_limbs, cfg.nwords)[2]
+                                  * 131072 / (k * 1e-3) / PEAK_MAD_PER_S}
+                elif name == "special_form":     # 2^401 - 1 through generic REDC and through the F-form multiply
+                    if left() < 25:
+                        raise TimeoutError("budget")
+                    e3 = pyecm.Engine((1 << 401) - 1, digitbits=52, device=devno)
+                    ms = {}
+                    for on in (False, True):
+                        e3.set_special_form(on)
+                        e3.set_lanes_per_curve(1)
+                        e3.build_curves(list(range(1000, 1000 + 131072)))
+                        e3.stage1(100000, sync=True)
+                        ms[on] = e3.last_kernel_ms()
+                    line[name] = {"N": "2^401-1", "curves": 131072, "B1": 100000, "generic_redc_kernel_ms": ms[False],
+                                  "special_form_kernel_ms": ms[True], "speedup": ms[False] / ms[True]}
+                    e3.close()
+            except TimeoutError:
+                line[name] = {"skipped": "time budget (%.0f s left)" % left()}
+            except Exception as ex:                 # an extra must never cost the headline line
+                line[name] = {"error": str(ex)}
+    if rank == 0:
+        line["wall_s"] = time.perf_counter() - t_begin
         print(json.dumps(line), flush=True)
     eng.close()
     if dist is not None:

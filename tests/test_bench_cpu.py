@@ -28,3 +28,41 @@ def test_work_per_curve_matches_survey_8d():
 
 def test_host_cores_positive():
     assert 1 <= _bench().host_cores() <= 64
+
+
+def test_plan_steps_keeps_request_when_it_fits_and_shrinks_otherwise():
+    b = _bench()
+    assert b.plan_steps(20, 5, 4.0, 400.0) == (4, 20)          # the driver's flags at 4 s per step: 96 s, fits
+    assert b.plan_steps(20, 5, 25.3, 400.0) == (1, 14)         # round 1's 131072-curve step would not have
+    assert b.plan_steps(20, 5, 500.0, 400.0) == (0, 1) or b.plan_steps(20, 5, 500.0, 400.0) == (1, 1)
+    assert b.plan_steps(3, 0, 1.0, 100.0) == (0, 3)
+
+
+def _run_bench(*args):
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(args), env=env, capture_output=True,
+                       text=True, timeout=600)
+    return p, [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
+
+
+def test_gpus_2_starts_two_ranks_and_prints_one_line():
+    """--gpus N without a torch.distributed environment: the parent (which touches no GPU) starts N ranks;
+    rank 0 prints the one JSON line with n_gpus = world size.  Engine stubbed (--no-engine), gloo."""
+    p, lines = _run_bench("--gpus", "2", "--backend", "gloo", "--no-engine", "--steps", "3", "--warmup", "2")
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert len(lines) == 1
+    assert lines[0]["n_gpus"] == 2 and lines[0]["steps"] == 3 and lines[0]["warmup"] == 2
+    assert lines[0]["config"]["curves_per_gpu"] == 4096 and lines[0]["scaling"] == "weak"
+    assert "rehearsal" in lines[0]
+
+
+def test_gpus_must_match_world_size():
+    import subprocess
+    import sys
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--no-engine"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "WORLD_SIZE" in p.stderr
