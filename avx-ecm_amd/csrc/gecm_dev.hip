@@ -53,6 +53,8 @@ struct gecm_dev {
     float last_ms = 0.f;
     bool timed = false;
     uint32_t *dModQ = nullptr;   // N and K' limbs padded to 40 each, for the eight-lane kernel
+    uint32_t *dRowC = nullptr;   // constants of the 32-lane kernel (gecm_dev_set_rowconst), GECM_ROW_KINDS x GECM_ROW_WORDS
+    int row_nq = 0;              // limbs per lane there; 0 = not available
     int fform = 0;        // +1 / -1: modulus is 2^k - 1 / 2^k + 1 and stage 1 uses the special multiply (gecm_dev_set_fform)
     int cus = 0;          // compute units of the device (4 SIMDs each)
     int last_lanes = 0;   // lanes per curve the last stage-1 launch used
@@ -119,6 +121,19 @@ extern "C" int gecm_dev_open(gecm_dev **out, int device, int nl, const uint32_t 
     return 0;
 }
 
+extern "C" int gecm_dev_set_rowconst(gecm_dev *d, int nq, const uint32_t *words)
+{
+    HIPCHK(hipSetDevice(d->device));
+    if (nq < 1 || nq > GECM_ROW_MAXNQ || 16 * nq > GECM_ROW_WORDS) {
+        g_err = "gecm_dev_set_rowconst: limbs per lane out of range";
+        return -2;
+    }
+    if (!d->dRowC) HIPCHK(hipMalloc(&d->dRowC, GECM_ROW_KINDS * GECM_ROW_WORDS * sizeof(uint32_t)));
+    HIPCHK(hipMemcpy(d->dRowC, words, GECM_ROW_KINDS * GECM_ROW_WORDS * sizeof(uint32_t), hipMemcpyHostToDevice));
+    d->row_nq = nq;
+    return 0;
+}
+
 static void free_state(gecm_dev *d)
 {
     (void)hipFree(d->dX); (void)hipFree(d->dZ); (void)hipFree(d->dS); (void)hipFree(d->dT0); (void)hipFree(d->dT1);
@@ -140,6 +155,7 @@ extern "C" void gecm_dev_close(gecm_dev *d)
     free_state(d);
     free_s2(d);
     (void)hipFree(d->dModQ);
+    (void)hipFree(d->dRowC);
     (void)hipFree(d->dKeep);
     (void)hipFree(d->dSteps);
     (void)hipFree(d->dFlags);
@@ -247,6 +263,10 @@ extern "C" int gecm_dev_auto_lanes(gecm_dev *d)
      * quads, the limbs of a residue spread over the quad, csrc/gecm_quad.hpp) — 1.5x the two-lane layout at 15
      * limbs, 2.2-2.4x at 30-37 limbs, up to 32 curves per CU; from 19 limbs up still 1.2-1.4x at 64 curves
      * per CU (tools/quad_check.py).  Generic moduli only. */
+    /* smaller still — at most 2 wavefronts of 2 curves on every SIMD: 32 lanes per curve (X and Z on two DPP rows,
+     * the limbs over the 16 lanes of a row, csrc/gecm_row.hpp), the layout that puts BASELINE configs[1]'s 4096
+     * curves on every SIMD of the chip twice */
+    if (!d->fform && d->row_nq && d->stride && d->stride <= (size_t)d->cus * 16) return 32;
     if (!d->fform && d->dModQ && d->stride && d->stride <= (size_t)d->cus * (d->nl >= 19 ? 64 : 32)) return 8;
     if (d->nl >= 26) return 2;
     const size_t full = (size_t)d->cus * 4 * 128;
@@ -276,8 +296,12 @@ extern "C" int gecm_dev_stage1(gecm_dev *d, int lanes_per_curve)
         return -2;
     }
     if (lanes_per_curve == 0) lanes_per_curve = gecm_dev_auto_lanes(d);
-    if (lanes_per_curve != 1 && lanes_per_curve != 2 && lanes_per_curve != 8) {
-        g_err = "gecm_dev_stage1: lanes per curve must be 0 (auto), 1, 2 or 8";
+    if (lanes_per_curve != 1 && lanes_per_curve != 2 && lanes_per_curve != 8 && lanes_per_curve != 32) {
+        g_err = "gecm_dev_stage1: lanes per curve must be 0 (auto), 1, 2, 8 or 32";
+        return -2;
+    }
+    if (lanes_per_curve == 32 && (d->fform || !d->row_nq)) {
+        g_err = "gecm_dev_stage1: no 32-lane kernel for this modulus";
         return -2;
     }
     if (lanes_per_curve == 8 && (d->fform || !d->dModQ)) {
@@ -290,7 +314,15 @@ extern "C" int gecm_dev_stage1(gecm_dev *d, int lanes_per_curve)
     switch (d->nl) {
 #define X(n)                                                                                     \
     case n:                                                                                      \
-        if (lanes_per_curve == 8) {                                                              \
+        if (lanes_per_curve == 32) {                                                             \
+            if (gecm_launch_stage1_row(d->stream, d->row_nq, d->dTape, (uint32_t)d->tape_len,    \
+                                       d->dX, d->dZ, d->dS, d->stride, (uint32_t)d->nl,          \
+                                       d->dRowC, d->rho)) {                                      \
+                g_err = "gecm_dev_stage1: no 32-lane kernel for this limb count";                \
+                return -2;                                                                       \
+            }                                                                                    \
+            gecm_launch_canon_##n(d->stream, &mc, d->dX, d->dZ, d->stride);                      \
+        } else if (lanes_per_curve == 8) {                                                              \
             if (gecm_launch_stage1_quad_##n(d->stream, &mc, d->dTape, (uint32_t)d->tape_len,     \
                                             d->dX, d->dZ, d->dS, d->stride, d->dModQ)) {         \
                 g_err = "gecm_dev_stage1: no eight-lane kernel for this limb count";             \

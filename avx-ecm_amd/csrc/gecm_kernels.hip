@@ -362,6 +362,13 @@ extern "C" int CAT(gecm_launch_stage1_quad_, GECM_NL)(void *stream, const gecm_m
 #endif
 }
 
+extern "C" void CAT(gecm_launch_canon_, GECM_NL)(void *stream, const gecm_modconst *mc, uint32_t *X, uint32_t *Z,
+                                                  size_t stride)
+{
+    hipLaunchKernelGGL(k_canon<GECM_NL>, dim3((unsigned)(stride / 64)), dim3(64), 0, (hipStream_t)stream, X, Z, stride,
+                       make_args<GECM_NL>(mc));
+}
+
 extern "C" void CAT(gecm_launch_from_mont_, GECM_NL)(void *stream, const gecm_modconst *mc, const uint32_t *X,
                                                       const uint32_t *Z, uint32_t *ox, uint32_t *oz,
                                                       size_t stride)

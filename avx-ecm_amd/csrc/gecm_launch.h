@@ -52,6 +52,8 @@ typedef struct {
     int gecm_launch_stage1_quad_##nl(void *stream, const gecm_modconst *mc, const uint32_t *tape,         \
                                      uint32_t tape_len, uint32_t *X, uint32_t *Z, const uint32_t *S,      \
                                      size_t stride, const uint32_t *modq);                                \
+    void gecm_launch_canon_##nl(void *stream, const gecm_modconst *mc, uint32_t *X, uint32_t *Z,          \
+                                size_t stride);                                                           \
     int gecm_fform_generic_limbs_##nl(void);                                                              \
     void gecm_launch_from_mont_##nl(void *stream, const gecm_modconst *mc, const uint32_t *X,             \
                                     const uint32_t *Z, uint32_t *ox, uint32_t *oz, size_t stride);        \
@@ -66,6 +68,15 @@ typedef struct {
                                    uint32_t *flags, size_t stride);
 GECM_NL_LIST(GECM_DECL)
 #undef GECM_DECL
+
+/* 32 lanes per curve (csrc/gecm_row.hpp, gecm_rowk.hip): nq = limbs per lane (1..GECM_ROW_MAXNQ), nl = limbs per
+ * residue of the device buffers, rc = device array of GECM_ROW_KINDS x GECM_ROW_WORDS constants.  Leaves lazy
+ * values in X, Z (run gecm_launch_canon_<nl> afterwards).  Returns -1 if nq is not built. */
+#define GECM_ROW_WORDS 48
+#define GECM_ROW_KINDS 5
+#define GECM_ROW_MAXNQ 3
+int gecm_launch_stage1_row(void *stream, int nq, const uint32_t *tape, uint32_t tape_len, uint32_t *X, uint32_t *Z,
+                           const uint32_t *S, size_t stride, uint32_t nl, const uint32_t *rc, uint32_t rho_n);
 
 #ifdef __cplusplus
 }

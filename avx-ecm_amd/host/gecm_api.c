@@ -67,7 +67,7 @@ struct gecm_ctx {
     int scan_valid[2];       /* the cached scan belongs to the current stage-1 / stage-2 result */
     uint64_t s2_ptadds, s2_numinv, s2_paired, s2_devinv;
     uint32_t s2_amin_last;
-    int lanes_per_curve;     /* 0 = auto, 1, 2 (gecm_set_lanes_per_curve) */
+    int lanes_per_curve;     /* 0 = auto, 1, 2, 8, 32 (gecm_set_lanes_per_curve) */
     /* F-form stage 1 for N | 2^k - 1: a second device context working modulo Mw = 2^k - 1
      * (csrc/gecm_field.hpp); results are brought back modulo N by ff_settle() */
     gecm_dev *dev_f;
@@ -153,6 +153,34 @@ static void ff_setup(gecm_ctx *c)
     c->ff_on = 1;
 }
 
+/* Constants of the 32-lanes-per-curve stage-1 kernel (csrc/gecm_row.hpp): it works modulo N' = m*N, the multiple
+ * of N that is -1 modulo 2^28 (the Montgomery digit is then the low limb itself), on L = 16*nq limbs with
+ * R' = 2^(28 L) >= 32 N'.  Entry factor R'^2/R mod N turns the buffers' x*R into x*R'; the exit multiply by R mod N
+ * (modulo N itself) turns it back.  Not an error if it cannot be set up: the other layouts cover every N. */
+static void row_setup(gecm_ctx *c)
+{
+    const int nl = c->nl;
+    const int nq = (nl + 1 + 15) / 16;               /* 28 (nl + 1) >= bits(N') + 5 */
+    if (nq > GECM_ROW_MAXNQ) return;
+    const int L = 16 * nq;
+    uint32_t w[GECM_ROW_KINDS * GECM_ROW_WORDS];
+    memset(w, 0, sizeof w);
+    mpl_t two28, inv, m, np, t;
+    mpl_set_u64(&two28, 1u << LIMB_BITS);
+    if (!mpl_invmod(&inv, &c->N, &two28)) return;
+    mpl_sub(&m, &two28, &inv);                        /* m = -N^-1 mod 2^28, in [1, 2^28) */
+    mpl_mul(&np, &m, &c->N);
+    if (mpl_bits(&np) + 5 > LIMB_BITS * L) return;
+    mpl_to_limbs32(w + 0 * GECM_ROW_WORDS, 1, L, LIMB_BITS, &np);
+    if (w[0] != (1u << LIMB_BITS) - 1u) return;
+    memcpy(w + 1 * GECM_ROW_WORDS, c->n28, (size_t)nl * sizeof(uint32_t));
+    pow2_mod(&t, (unsigned)(2 * LIMB_BITS * L - LIMB_BITS * nl), &c->N);
+    mpl_to_limbs32(w + 2 * GECM_ROW_WORDS, 1, nl, LIMB_BITS, &t);
+    memcpy(w + 3 * GECM_ROW_WORDS, c->one28, (size_t)nl * sizeof(uint32_t));
+    memcpy(w + 4 * GECM_ROW_WORDS, c->kp28, (size_t)nl * sizeof(uint32_t));
+    (void)gecm_dev_set_rowconst(c->dev, nq, w);
+}
+
 int gecm_create(gecm_ctx **out, int device, const char *n_str, int digitbits)
 {
     if (!out || !n_str || (digitbits != 52 && digitbits != 32)) {
@@ -222,6 +250,7 @@ int gecm_create(gecm_ctx **out, int device, const char *n_str, int digitbits)
     mpl_mulmod(&t, &t, &c->rint_mod_n, &c->N);
     mpl_to_limbs32(c->r3_28, 1, nl, LIMB_BITS, &t);
     gecm_dev_set_s2const(c->dev, c->r3_28, (uint32_t)(2 * c->nbits + 2));
+    row_setup(c);
     ff_setup(c);
     *out = c;
     return GECM_OK;
@@ -673,7 +702,8 @@ int gecm_stage1(gecm_ctx *c, uint64_t B1)
     c->scan_valid[0] = c->scan_valid[1] = 0;
     /* For a batch small enough for the eight-lane layout (generic moduli only) that layout beats the special
      * multiply in its two-lane form: 1.5x against 1.4x at 15 limbs, 2.2-2.4x at 30-37 limbs. */
-    const int small_batch = c->lanes_per_curve == 8 || (c->lanes_per_curve == 0 && gecm_dev_auto_lanes(c->dev) == 8);
+    const int want = c->lanes_per_curve ? c->lanes_per_curve : gecm_dev_auto_lanes(c->dev);
+    const int small_batch = want == 8 || want == 32;
     if (c->dev_f && c->ff_on && c->ff_loaded && !small_batch) {
         /* N | 2^k - 1: run the chain modulo 2^k - 1 with the F-form multiply; ff_settle brings X, Z back */
         if (c->ff_tape_B1 != B1) {
@@ -709,7 +739,10 @@ int gecm_get_special_form(const gecm_ctx *c, int *k, int *limbs)
 
 int gecm_set_lanes_per_curve(gecm_ctx *c, int lanes)
 {
-    if (!c || (lanes != 0 && lanes != 1 && lanes != 2 && lanes != 8)) { set_err("gecm_set_lanes_per_curve: lanes must be 0 (auto), 1, 2 or 8"); return GECM_ERR_ARG; }
+    if (!c || (lanes != 0 && lanes != 1 && lanes != 2 && lanes != 8 && lanes != 32)) {
+        set_err("gecm_set_lanes_per_curve: lanes must be 0 (auto), 1, 2, 8 or 32");
+        return GECM_ERR_ARG;
+    }
     c->lanes_per_curve = lanes;
     return GECM_OK;
 }
