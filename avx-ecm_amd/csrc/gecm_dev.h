@@ -9,6 +9,7 @@
 #define GECM_DEV_H
 #include <stddef.h>
 #include <stdint.h>
+#include "gecm_rowk.h"
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -38,9 +39,6 @@ int gecm_dev_set_tape(gecm_dev *d, const uint8_t *tape, size_t len);
  * too small to fill the chip), 0 = let the device layer choose from the batch size and CU count */
 int gecm_dev_stage1(gecm_dev *d, int lanes_per_curve);
 int gecm_dev_auto_lanes(gecm_dev *d);
-#define GECM_ROW_WORDS 48     /* same values in gecm_launch.h */
-#define GECM_ROW_KINDS 5
-#define GECM_ROW_MAXNQ 3
 /* constants of the 32-lanes-per-curve kernel (csrc/gecm_row.hpp): nq limbs per lane, GECM_ROW_KINDS x
  * GECM_ROW_WORDS words (N' = m*N = -1 mod 2^28; N; entry factor; R mod N; K' of N), limb j at word j */
 int gecm_dev_set_rowconst(gecm_dev *d, int nq, const uint32_t *words);

@@ -263,15 +263,26 @@ extern "C" int gecm_dev_auto_lanes(gecm_dev *d)
      * quads, the limbs of a residue spread over the quad, csrc/gecm_quad.hpp) — 1.5x the two-lane layout at 15
      * limbs, 2.2-2.4x at 30-37 limbs, up to 32 curves per CU; from 19 limbs up still 1.2-1.4x at 64 curves
      * per CU (tools/quad_check.py).  Generic moduli only. */
-    /* smaller still — at most 2 wavefronts of 2 curves on every SIMD: 32 lanes per curve (X and Z on two DPP rows,
+    /* smaller still — at most 4 wavefronts of 2 curves on every SIMD: 32 lanes per curve (X and Z on two DPP rows,
      * the limbs over the 16 lanes of a row, csrc/gecm_row.hpp), the layout that puts BASELINE configs[1]'s 4096
-     * curves on every SIMD of the chip twice */
-    if (!d->fform && d->row_nq && d->stride && d->stride <= (size_t)d->cus * 16) return 32;
+     * curves on every SIMD of the chip twice: 1.8x the eight-lane layout at 4096 curves (415 and 831 bits), 1.3x
+     * at 1023 bits, 1.05x at 8192 curves, slower from there on (tools/row_check.py).  Below 10 limbs the
+     * 16 lanes of a row are mostly padding and the eight-lane layout wins. */
+    if (!d->fform && d->row_nq && d->nl >= 10 && d->stride && d->stride <= (size_t)d->cus * 32) return 32;
     if (!d->fform && d->dModQ && d->stride && d->stride <= (size_t)d->cus * (d->nl >= 19 ? 64 : 32)) return 8;
     if (d->nl >= 26) return 2;
     const size_t full = (size_t)d->cus * 4 * 128;
     const size_t r = d->stride % full;
     return (r == 0 || r > full / 4 * 3) ? 1 : 2;
+}
+
+/* 32-lane kernel: operand broadcasts through the LDS crossbar from 3 wavefronts per SIMD up (tools/row_check.py);
+ * GECM_ROW_ALDS=0/1 overrides for experiments */
+static int row_a_lds(const gecm_dev *d)
+{
+    const char *e = getenv("GECM_ROW_ALDS");
+    if (e && (e[0] == '0' || e[0] == '1')) return e[0] == '1';
+    return d->stride > (size_t)d->cus * 16;
 }
 
 extern "C" int gecm_dev_last_lanes(gecm_dev *d) { return d->last_lanes; }
@@ -317,7 +328,8 @@ extern "C" int gecm_dev_stage1(gecm_dev *d, int lanes_per_curve)
         if (lanes_per_curve == 32) {                                                             \
             if (gecm_launch_stage1_row(d->stream, d->row_nq, d->dTape, (uint32_t)d->tape_len,    \
                                        d->dX, d->dZ, d->dS, d->stride, (uint32_t)d->nl,          \
-                                       d->dRowC, d->rho)) {                                      \
+                                       d->dRowC, d->rho,                                 \
+                                       row_a_lds(d))) {                                      \
                 g_err = "gecm_dev_stage1: no 32-lane kernel for this limb count";                \
                 return -2;                                                                       \
             }                                                                                    \

@@ -69,15 +69,6 @@ typedef struct {
 GECM_NL_LIST(GECM_DECL)
 #undef GECM_DECL
 
-/* 32 lanes per curve (csrc/gecm_row.hpp, gecm_rowk.hip): nq = limbs per lane (1..GECM_ROW_MAXNQ), nl = limbs per
- * residue of the device buffers, rc = device array of GECM_ROW_KINDS x GECM_ROW_WORDS constants.  Leaves lazy
- * values in X, Z (run gecm_launch_canon_<nl> afterwards).  Returns -1 if nq is not built. */
-#define GECM_ROW_WORDS 48
-#define GECM_ROW_KINDS 5
-#define GECM_ROW_MAXNQ 3
-int gecm_launch_stage1_row(void *stream, int nq, const uint32_t *tape, uint32_t tape_len, uint32_t *X, uint32_t *Z,
-                           const uint32_t *S, size_t stride, uint32_t nl, const uint32_t *rc, uint32_t rho_n);
-
 #ifdef __cplusplus
 }
 #endif

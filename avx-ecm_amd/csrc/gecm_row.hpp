@@ -25,7 +25,12 @@
 // (R' = 2^(448*NQ) inside), and k_canon makes the exit values canonical.
 #pragma once
 #include "gecm_curve.hpp"
-#include "gecm_launch.h"
+#include "gecm_rowk.h"
+
+#ifndef GECM_ROW_DPP_ROWS
+#define GECM_ROW_DPP_ROWS 48    /* rows of a multiply whose operand limb is broadcast by DPP (the rest: ds_swizzle).
+                                   Measured at 4096 curves x 415 bits, B1 = 1e5: all rows 271 ms, 4 rows 279 ms */
+#endif
 
 template <int NQ>
 struct FeR {
@@ -52,6 +57,13 @@ __device__ __forceinline__ uint32_t row_bcast(uint32_t x)
 {
     return row_dpp<GECM_DPP_ROW_NEWBCAST + I>(x);
 }
+// every lane <- lane I of its row, through the LDS crossbar (ds_swizzle, bit mode: lane = (lane & 0x10) | I):
+// no VALU issue slot, the latency is covered by issuing all broadcasts of a multiply before its first row
+template <int I>
+__device__ __forceinline__ uint32_t row_bcast_lds(uint32_t x)
+{
+    return (uint32_t)__builtin_amdgcn_ds_swizzle((int)x, 0x10 | (I << 5));
+}
 __device__ __forceinline__ uint32_t other_row(uint32_t x)       // lane <-> lane ^ 16: the other coordinate
 {
     return (uint32_t)__builtin_amdgcn_ds_swizzle((int)x, 0x401F /* bit mode: and 0x1f, or 0, xor 0x10 */);
@@ -72,9 +84,20 @@ __device__ __forceinline__ int64_t smad16(int32_t x, int64_t add)    // 16 * x +
     return r;
 }
 
+// 16 * x + add, then + y * z: the hand-over at the end of a row and the first multiply-add of the next row in one
+// asm statement (the compiler pads a wait state between two asm statements)
+__device__ __forceinline__ int64_t smad16_smad(int32_t x, int64_t add, int32_t y, int32_t z)
+{
+    int64_t r;
+    asm("v_mad_i64_i32 %0, vcc, %1, 16, %2\n\tv_mad_i64_i32 %0, vcc, %3, %4, %0" : "=&v"(r) : "v"(x), "v"(add), "v"(y), "v"(z) : "vcc");
+    return r;
+}
+
 // r = a*b/R' mod (modulus of m), R' = 2^(448*NQ).  Operand limbs |.| < 2^29; result limbs in [-2^27-4, 2^27+4]
 // (top limb: whatever the value needs), |result| < |a||b|/R' + modulus.
-template <int NQ, bool RHO1>
+// ALDS: the limbs of a are broadcast through the LDS crossbar (ds_swizzle: no VALU issue slot, best from 3 wavefronts
+// per SIMD up) instead of DPP row_newbcast (which sits in a wait state the digit broadcast needs anyway: best at 2).
+template <int NQ, bool RHO1, bool ALDS>
 __device__ __forceinline__ void fer_mul(FeR<NQ> &r, const FeR<NQ> &a, const FeR<NQ> &b, const RowMod<NQ> &m)
 {
     int32_t a4[NQ], b4[NQ];
@@ -83,27 +106,68 @@ __device__ __forceinline__ void fer_mul(FeR<NQ> &r, const FeR<NQ> &a, const FeR<
         a4[t] = (int32_t)((uint32_t)a.v[t] << 2);
         b4[t] = (int32_t)((uint32_t)b.v[t] << 2);
     }
+    // The limbs of 4a reach the lanes of the row one per row of the multiply.  A DPP read of a register that a
+    // VALU instruction has just written needs two independent instructions in between; a row has two such places
+    // (multiply-add -> digit broadcast, multiply-add -> hand-over), i.e. four instruction slots, and the requests
+    // for later rows' limbs are what fills them:
+    //   * rows 0 .. ND-1 get their limb by DPP row_newbcast, requested one row ahead (a VALU instruction, ready at
+    //     once: the operand a is only known when the multiply starts);
+    //   * rows ND .. get theirs by ds_swizzle through the LDS crossbar (no VALU issue slot, but ~70 cycles), all
+    //     requested in the slots of the first rows.
+    // ALDS (3 or more wavefronts per SIMD hide the start-up latency): every limb by ds_swizzle, requested up front.
+    constexpr int ROWS = 16 * NQ;
+    constexpr int ND = ALDS ? 0 : (GECM_ROW_DPP_ROWS < ROWS ? GECM_ROW_DPP_ROWS : ROWS);
+    int32_t Ab[ROWS];
+    auto request = [&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        if constexpr (j < ND) Ab[j] = (int32_t)row_bcast<j / NQ>((uint32_t)a4[j % NQ]);
+        else if constexpr (j < ROWS) Ab[j] = (int32_t)row_bcast_lds<j / NQ>((uint32_t)a4[j % NQ]);
+    };
+    // slot plan: row i < ND: first place = DPP request for row i+1 (if that is a DPP row) else one LDS request;
+    // second place = two LDS requests.  Rows >= ND: one LDS request in the first place, two in the second, until
+    // all are out.  LDS requests go out in row order (the crossbar answers in order).
+    if constexpr (ALDS) static_for<0, ROWS>(request);
+    else request(IC<0>{});
     int64_t T[NQ];                    // 16 x the window; logical slot t of row i lives in T[(t + i) % NQ]
 #pragma unroll
     for (int t = 0; t < NQ; t++) T[t] = 0;
-    static_for<0, 16 * NQ>([&](auto ic) {
+    static_for<0, ROWS>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         constexpr int rot = i % NQ, nxt = (i + 1) % NQ;
-        const int32_t A = (int32_t)row_bcast<i / NQ>((uint32_t)a4[i % NQ]);
+        // LDS requests issued before this row: 2 per row in the second place, plus 1 in the first place of every
+        // row from ND-1 on (whose next row is not a DPP row)
+        constexpr int first_lds = (i + 1 < ND) ? 0 : 1;
+        constexpr int before = ND + 2 * i + (i >= ND ? i - ND + 1 : 0);
+        // (the multiply-add into the lowest slot was fused with the previous row's hand-over, except in row 0)
+        if constexpr (i == 0) smad(T[rot], Ab[0], b4[0]);
 #pragma unroll
-        for (int t = 0; t < NQ; t++) smad(T[(t + rot) % NQ], A, b4[t]);
+        for (int t = 1; t < NQ; t++) smad(T[(t + rot) % NQ], Ab[i], b4[t]);
+        if constexpr (!ALDS) {
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (i + 1 < ND) request(IC<i + 1>{});
+            else request(IC<before>{});
+            __builtin_amdgcn_sched_barrier(0);
+        }
         uint32_t qs = (uint32_t)T[rot];                     // 16 x (column mod 2^28)
         if (!RHO1) qs *= m.rho;                             // 16 x the digit (mod 2^32)
         const uint32_t Q = row_bcast<0>(qs);
 #pragma unroll
         for (int t = 0; t < NQ; t++) umad(T[(t + rot) % NQ], Q, m.n[t]);
+        if constexpr (!ALDS) {
+            __builtin_amdgcn_sched_barrier(0);
+            request(IC<before + first_lds>{});
+            request(IC<before + first_lds + 1>{});
+            __builtin_amdgcn_sched_barrier(0);
+        }
         // the window moves down one limb: the low register of the lowest slot (zero on lane 0 by the choice of
         // the digit) becomes the top slot of the lane below, its high register (the part above 28 bits) is
-        // added, times 16, to this lane's next slot
+        // added, times 16, to this lane's next slot — which is the next row's lowest slot and gets that row's
+        // first product in the same statement
         const int32_t hi = (int32_t)(T[rot] >> 32);
         const uint32_t lo = row_dpp<GECM_DPP_ROW_SHL1>((uint32_t)T[rot]);
         T[rot] = (int64_t)(uint64_t)lo;
-        T[nxt] = smad16(hi, T[nxt]);
+        if constexpr (i + 1 < ROWS) T[nxt] = smad16_smad(hi, T[nxt], Ab[i + 1], b4[0]);
+        else T[nxt] = smad16(hi, T[nxt]);
     });
     // balanced normalisation.  Inside the lane the slots still hold whole column sums (only the lowest slot is
     // folded per row), so the carry runs through them in 64 bits; the top slot is a fresh 28-bit hand-over, so
@@ -124,6 +188,24 @@ __device__ __forceinline__ void fer_mul(FeR<NQ> &r, const FeR<NQ> &a, const FeR<
     for (int t = 1; t < NQ; t++) r.v[t] = lo[t];
 }
 
+// A point coordinate as the tape interpreter keeps it: its own limbs and the three combinations with the other
+// coordinate that the point formulas read (ecm.c:407-457 split into X and Z halves as in gecm_quad.hpp), all made
+// ONCE when the point is created, from one exchange between the X row and the Z row.  The exchange goes through
+// the LDS crossbar (ds_swizzle, lane ^ 16): no VALU issue slot, which is what a batch at 2 wavefronts per SIMD is
+// short of (v_permlane16_swap, measured: 7% slower at 4096 curves).
+template <int NQ>
+struct PtR {
+    FeR<NQ> own;   // X rows: X        Z rows: Z
+    FeR<NQ> sd;    // X rows: Z + X    Z rows: X - Z      (the operand this point gives as "A")
+    FeR<NQ> ds;    // X rows: X - Z    Z rows: Z + X      (as "B")
+    FeR<NQ> oth;   // X rows: Z        Z rows: X          (as the difference point "C")
+};
+
+struct RowSign {
+    uint32_t mz, bz;   // Z rows: -1, 1    X rows: 0, 0      (x ^ mz) + bz = -x on Z rows
+    uint32_t mx, bx;   // X rows: -1, 1    Z rows: 0, 0
+};
+
 template <int NQ>
 __device__ __forceinline__ void fer_other(FeR<NQ> &r, const FeR<NQ> &a)
 {
@@ -131,49 +213,45 @@ __device__ __forceinline__ void fer_other(FeR<NQ> &r, const FeR<NQ> &a)
     for (int t = 0; t < NQ; t++) r.v[t] = (int32_t)other_row((uint32_t)a.v[t]);
 }
 
-// r = x + y on lanes with neg == false, x - y on lanes with neg == true
+// r = oth + own on X rows, oth - own on Z rows
 template <int NQ>
-__device__ __forceinline__ void fer_addsub_lane(FeR<NQ> &r, const FeR<NQ> &x, const FeR<NQ> &y, bool neg)
+__device__ __forceinline__ void fer_sum_diff(FeR<NQ> &r, const FeR<NQ> &oth, const FeR<NQ> &own, const RowSign &g)
 {
 #pragma unroll
-    for (int t = 0; t < NQ; t++) r.v[t] = x.v[t] + (neg ? -y.v[t] : y.v[t]);
+    for (int t = 0; t < NQ; t++) r.v[t] = (int32_t)((uint32_t)oth.v[t] + ((uint32_t)own.v[t] ^ g.mz) + g.bz);
 }
 
-// the point arithmetic of gecm_quad.hpp (ecm.c:407-457 split into its X and Z halves), on rows
 template <int NQ>
-__device__ __forceinline__ void row_sum_diff(FeR<NQ> &r, const FeR<NQ> &own, bool isZ)
+__device__ __forceinline__ void row_forms(PtR<NQ> &p, const RowSign &g)
 {
-    FeR<NQ> oth;
-    fer_other<NQ>(oth, own);
-    fer_addsub_lane<NQ>(r, oth, own, isZ);            // X rows: Z + X      Z rows: X - Z
+    fer_other<NQ>(p.oth, p.own);
+    fer_sum_diff<NQ>(p.sd, p.oth, p.own, g);
+#pragma unroll
+    for (int t = 0; t < NQ; t++)                  // own - oth on X rows, own + oth on Z rows
+        p.ds.v[t] = (int32_t)((uint32_t)p.own.v[t] + ((uint32_t)p.oth.v[t] ^ g.mx) + g.bx);
 }
 
-template <int NQ>
-__device__ __forceinline__ void row_diff_sum(FeR<NQ> &r, const FeR<NQ> &own, bool isZ)
-{
-    FeR<NQ> oth;
-    fer_other<NQ>(oth, own);
-    fer_addsub_lane<NQ>(r, own, oth, !isZ);           // X rows: X - Z      Z rows: Z + X
-}
-
-template <int NQ>
-__device__ __forceinline__ void row_add(FeR<NQ> &T, const FeR<NQ> &fB, const FeR<NQ> &fA, const FeR<NQ> &c, bool isZ,
-                                        const RowMod<NQ> &m)
+// T = A + B with difference C (vec_add, ecm.c:407-443): fB = B.ds, fA = A.sd, c = C.oth
+template <int NQ, bool ALDS>
+__device__ __forceinline__ void row_add(PtR<NQ> &T, const FeR<NQ> &fB, const FeR<NQ> &fA, const FeR<NQ> &c, bool isZ,
+                                        const RowSign &g, const RowMod<NQ> &m)
 {
     FeR<NQ> w, t, e;
-    fer_mul<NQ, true>(w, fB, fA, m);                  // X: U      Z: V
+    fer_mul<NQ, true, ALDS>(w, fB, fA, m);            // X: U      Z: V
     fer_other<NQ>(t, w);
-    fer_addsub_lane<NQ>(e, t, w, isZ);                // X: V + U  Z: U - V
-    fer_mul<NQ, true>(e, e, e, m);
-    fer_other<NQ>(t, c);                              // X: C.Z    Z: C.X
-    fer_mul<NQ, true>(T, e, t, m);
+    fer_sum_diff<NQ>(e, t, w, g);                     // X: V + U  Z: U - V
+    fer_mul<NQ, true, ALDS>(e, e, e, m);
+    fer_mul<NQ, true, ALDS>(T.own, e, c, m);
+    row_forms<NQ>(T, g);
 }
 
-template <int NQ>
-__device__ __forceinline__ void row_dup(FeR<NQ> &D, const FeR<NQ> &fA, const FeR<NQ> &s4, bool isZ, const RowMod<NQ> &m)
+// D = 2A (vec_duplicate, ecm.c:445-457): fA = A.sd, s4 = (A+2)/4 of the curve
+template <int NQ, bool ALDS>
+__device__ __forceinline__ void row_dup(PtR<NQ> &D, const FeR<NQ> &fA, const FeR<NQ> &s4, bool isZ, const RowSign &g,
+                                        const RowMod<NQ> &m)
 {
     FeR<NQ> q, t, w, p1, p2, r1;
-    fer_mul<NQ, true>(q, fA, fA, m);                  // X: U = (x+z)^2    Z: V = (x-z)^2
+    fer_mul<NQ, true, ALDS>(q, fA, fA, m);            // X: U = (x+z)^2    Z: V = (x-z)^2
     fer_other<NQ>(t, q);                              // X: V              Z: U
 #pragma unroll
     for (int i = 0; i < NQ; i++) {
@@ -181,12 +259,13 @@ __device__ __forceinline__ void row_dup(FeR<NQ> &D, const FeR<NQ> &fA, const FeR
         p1.v[i] = isZ ? s4.v[i] : q.v[i];
         p2.v[i] = isZ ? w.v[i] : t.v[i];
     }
-    fer_mul<NQ, true>(r1, p1, p2, m);                 // X: U*V            Z: s*w
+    fer_mul<NQ, true, ALDS>(r1, p1, p2, m);           // X: U*V            Z: s*w
 #pragma unroll
     for (int i = 0; i < NQ; i++) t.v[i] = r1.v[i] + q.v[i];     // Z: s*w + V
-    fer_mul<NQ, true>(t, t, w, m);                    // Z: (s*w + V)*w
+    fer_mul<NQ, true, ALDS>(t, t, w, m);              // Z: (s*w + V)*w
 #pragma unroll
-    for (int i = 0; i < NQ; i++) D.v[i] = isZ ? t.v[i] : r1.v[i];
+    for (int i = 0; i < NQ; i++) D.own.v[i] = isZ ? t.v[i] : r1.v[i];
+    row_forms<NQ>(D, g);
 }
 
 template <int NQ>
@@ -200,12 +279,12 @@ __device__ __forceinline__ void fer_load(FeR<NQ> &r, const uint32_t *__restrict_
     }
 }
 
-// run_tape_quad of gecm_quad.hpp on rows: A, B, C are this lane's limbs of its coordinate.
-template <int NQ>
-__device__ __forceinline__ void run_tape_row(const uint32_t *__restrict__ tape, uint32_t tape_len, FeR<NQ> &A,
-                                             const FeR<NQ> &s4, bool isZ, const RowMod<NQ> &m)
+// run_tape_quad of gecm_quad.hpp on rows: A, B, C are this lane's limbs of its coordinate (and their forms).
+template <int NQ, bool ALDS>
+__device__ __forceinline__ void run_tape_row(const uint32_t *__restrict__ tape, uint32_t tape_len, PtR<NQ> &A,
+                                             const FeR<NQ> &s4, bool isZ, const RowSign &g, const RowMod<NQ> &m)
 {
-    FeR<NQ> B = A, C = A;
+    PtR<NQ> B = A, C = A;
     auto fetch = [&](uint32_t pc) -> uint32_t {
         uint32_t w = tape[pc >> 2];
         return __builtin_amdgcn_readfirstlane((w >> ((pc & 3u) * 8u)) & 0xffu);
@@ -216,14 +295,12 @@ __device__ __forceinline__ void run_tape_row(const uint32_t *__restrict__ tape, 
         nxt = (pc + 1 < tape_len) ? fetch(pc + 1) : GECM_OP_NOP;
         while ((op & ~GECM_OP_SWAP) == (GECM_OP_STEP | GECM_OP_RULE3)) {
             if (op & GECM_OP_SWAP) {
-                FeR<NQ> t = A;
+                PtR<NQ> t = A;
                 A = B;
                 B = t;
             }
-            FeR<NQ> fA, fB, T;
-            row_diff_sum<NQ>(fB, B, isZ);
-            row_sum_diff<NQ>(fA, A, isZ);
-            row_add<NQ>(T, fB, fA, C, isZ, m);
+            PtR<NQ> T;
+            row_add<NQ, ALDS>(T, B.ds, A.sd, C.oth, isZ, g, m);
             C = B;
             B = T;
             pc++;
@@ -236,16 +313,16 @@ __device__ __forceinline__ void run_tape_row(const uint32_t *__restrict__ tape, 
         const bool do_add = op != GECM_OP_PRAC_BEGIN;
         const bool do_dup = op != GECM_OP_PRAC_END;
         if (is_step && (op & GECM_OP_SWAP)) {
-            FeR<NQ> t = A;
+            PtR<NQ> t = A;
             A = B;
             B = t;
         }
         if (is_step && rule == GECM_OP_RULE5) {
-            FeR<NQ> t = B;
+            PtR<NQ> t = B;
             B = C;
             C = t;
         } else if (is_step && rule == GECM_OP_RULE9) {
-            FeR<NQ> t = A;
+            PtR<NQ> t = A;
             A = B;
             B = C;
             C = t;
@@ -253,17 +330,9 @@ __device__ __forceinline__ void run_tape_row(const uint32_t *__restrict__ tape, 
             B = A;
             C = A;
         }
-        FeR<NQ> T, D;
-        {
-            FeR<NQ> fA;
-            row_sum_diff<NQ>(fA, A, isZ);
-            if (do_add) {
-                FeR<NQ> fB;
-                row_diff_sum<NQ>(fB, B, isZ);
-                row_add<NQ>(T, fB, fA, C, isZ, m);
-            }
-            if (do_dup) row_dup<NQ>(D, fA, s4, isZ, m);
-        }
+        PtR<NQ> T, D;
+        if (do_add) row_add<NQ, ALDS>(T, B.ds, A.sd, C.oth, isZ, g, m);
+        if (do_dup) row_dup<NQ, ALDS>(D, A.sd, s4, isZ, g, m);
         if (op == GECM_OP_PRAC_END) {
             A = T;
         } else if (op == GECM_OP_PRAC_BEGIN) {
@@ -272,12 +341,12 @@ __device__ __forceinline__ void run_tape_row(const uint32_t *__restrict__ tape, 
             B = T;
             A = D;
         } else if (rule == GECM_OP_RULE5) {
-            FeR<NQ> t = C;
+            PtR<NQ> t = C;
             C = T;
             B = t;
             A = D;
         } else {
-            FeR<NQ> oldA = C;
+            PtR<NQ> oldA = C;
             C = T;
             B = D;
             A = oldA;
@@ -288,10 +357,10 @@ __device__ __forceinline__ void run_tape_row(const uint32_t *__restrict__ tape, 
 // Constants of the row kernel, one array of GECM_ROW_WORDS words per kind, limb j at word j (zero padded):
 //   [0] N' = m*N, = -1 mod 2^28      [1] N      [2] c_in = 2^28 * R' mod N (entry conversion)
 //   [3] R mod N (exit conversion)    [4] K' of N (bias that makes the exit value's limbs non-negative)
-// (GECM_ROW_WORDS, GECM_ROW_KINDS: gecm_launch.h)
+// (GECM_ROW_WORDS, GECM_ROW_KINDS: gecm_rowk.h)
 
 // The whole stage-1 kernel body for one lane.  nl = limbs per residue in the device buffers (R = 2^(28*nl)).
-template <int NQ>
+template <int NQ, bool ALDS>
 __device__ __forceinline__ void stage1_row(const uint32_t *__restrict__ tape, uint32_t tape_len, uint32_t *__restrict__ X,
                                            uint32_t *__restrict__ Z, const uint32_t *__restrict__ S, size_t stride,
                                            uint32_t nl, const uint32_t *__restrict__ rc, uint32_t rho_n)
@@ -313,13 +382,20 @@ __device__ __forceinline__ void stage1_row(const uint32_t *__restrict__ tape, ui
     }
     mp.rho = 1u;
     mn.rho = rho_n;
-    FeR<NQ> P, s4, t;
+    PtR<NQ> P;
+    FeR<NQ> s4, t;
     fer_load<NQ>(t, mine, stride, cidx, l, nl);
-    fer_mul<NQ, true>(P, t, cin, mp);                       // x*R -> x*R' (mod N')
+    fer_mul<NQ, true, ALDS>(P.own, t, cin, mp);             // x*R -> x*R' (mod N')
+    RowSign g;
+    g.mz = isZ ? 0xffffffffu : 0u;
+    g.bz = isZ ? 1u : 0u;
+    g.mx = ~g.mz;
+    g.bx = 1u - g.bz;
+    row_forms<NQ>(P, g);
     fer_load<NQ>(t, S, stride, cidx, l, nl);
-    fer_mul<NQ, true>(s4, t, cin, mp);
-    run_tape_row<NQ>(tape, tape_len, P, s4, isZ, mp);
-    fer_mul<NQ, false>(t, P, one, mn);                      // x*R' -> x*R (mod N), in (-N/16, 17N/16)
+    fer_mul<NQ, true, ALDS>(s4, t, cin, mp);
+    run_tape_row<NQ, ALDS>(tape, tape_len, P, s4, isZ, g, mp);
+    fer_mul<NQ, false, ALDS>(t, P.own, one, mn);                    // x*R' -> x*R (mod N), in (-N/16, 17N/16)
     // + K' (a multiple of N with every limb >= 2^28 - 1): all limbs positive; then one carry-save pass
     uint32_t u[NQ];
 #pragma unroll

@@ -1,0 +1,26 @@
+/* gecm_rowk.h — launcher of the 32-lanes-per-curve stage-1 kernels (csrc/gecm_row.hpp, gecm_rowk.hip): one entry
+ * point for every limb count. */
+#ifndef GECM_ROWK_H
+#define GECM_ROWK_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* 32 lanes per curve (csrc/gecm_row.hpp, gecm_rowk.hip): nq = limbs per lane (1..GECM_ROW_MAXNQ), nl = limbs per
+ * residue of the device buffers, rc = device array of GECM_ROW_KINDS x GECM_ROW_WORDS constants.  Leaves lazy
+ * values in X, Z (run gecm_launch_canon_<nl> afterwards).  a_lds != 0: operand limbs are broadcast through the LDS
+ * crossbar instead of DPP (faster from 3 wavefronts per SIMD up).  Returns -1 if nq is not built. */
+#define GECM_ROW_WORDS 48     /* words per constant array: limbs 0 .. 16*nq-1, zero padded */
+#define GECM_ROW_KINDS 5
+#define GECM_ROW_MAXNQ 3
+int gecm_launch_stage1_row(void *stream, int nq, const uint32_t *tape, uint32_t tape_len, uint32_t *X, uint32_t *Z,
+                           const uint32_t *S, size_t stride, uint32_t nl, const uint32_t *rc, uint32_t rho_n,
+                           int a_lds);
+
+
+#ifdef __cplusplus
+}
+#endif
+#endif

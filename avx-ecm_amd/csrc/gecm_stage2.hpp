@@ -162,7 +162,9 @@ __device__ __noinline__ bool fe_invert(Fe<NL> &r, Fe<NL> &g, const Fe<NL> &x, co
 }
 
 // Montgomery form of the inverse of a Montgomery-form value: a = x R  ->  x^-1 R.
-// On failure r = 0 and *fail receives gcd(x R mod N, N) = gcd(x, N) (first failure wins).
+// On failure r = 0 and *fail receives gcd(x R mod N, N) = gcd(x, N).  The LAST failure wins, as in the reference,
+// which overwrites its accumulator with the gcd every time an inversion fails (ecm.c:1925-1939); the host makes the
+// last chunk of giant steps coincide with the reference's last batch (gecm_stage2_pair).
 template <int NL>
 __device__ __forceinline__ void fe_inv_mont(Fe<NL> &r, const Fe<NL> &a, const S2Const<NL> &k, uint32_t *__restrict__ fail,
                                             size_t stride, uint32_t idx)
@@ -174,12 +176,10 @@ __device__ __forceinline__ void fe_inv_mont(Fe<NL> &r, const Fe<NL> &a, const S2
     if (!ok) {
 #pragma unroll
         for (int i = 0; i < NL; i++) r.v[i] = 0;
-        if (fail[idx] == 0) {                     // limb 0 of the record doubles as the flag
-            bool nz = false;
+        bool nz = false;
 #pragma unroll
-            for (int i = 0; i < NL; i++) nz = nz || g.v[i] != 0;
-            if (nz) fe_store(fail, stride, idx, g);
-        }
+        for (int i = 0; i < NL; i++) nz = nz || g.v[i] != 0;
+        if (nz) fe_store(fail, stride, idx, g);
     }
 }
 

@@ -530,18 +530,19 @@ static int host_threads(void)
 int gecm_build_curves(gecm_ctx *c, const uint64_t *sigma, size_t batch)
 {
     if (!c || !sigma || batch == 0) { set_err("gecm_build_curves: bad argument"); return GECM_ERR_ARG; }
+    /* inputs are checked before the context takes the new batch: after an error it holds no batch at all (the
+     * phase functions then return GECM_ERR_STATE instead of running on memory nothing was uploaded to) */
+    for (size_t i = 0; i < batch; i++)
+        if (sigma[i] < 6) { set_err("gecm_build_curves: sigma[%zu] < 6", i); return GECM_ERR_ARG; }
     int rc = alloc_batch(c, batch);
     if (rc) return rc;
-    for (size_t i = 0; i < batch; i++) {
-        if (sigma[i] < 6) { set_err("gecm_build_curves: sigma[%zu] < 6", i); return GECM_ERR_ARG; }
-        c->sigma[i] = sigma[i];
-    }
+    memcpy(c->sigma, sigma, batch * sizeof(uint64_t));
     size_t words = (size_t)c->nl * batch;
     uint32_t *hX = (uint32_t *)calloc(words * 3, 4);
-    if (!hX) return GECM_ERR_NOMEM;
+    if (!hX) { free_batch(c); return GECM_ERR_NOMEM; }
     const size_t fwords = c->dev_f ? (size_t)c->ff_nl * batch : 0;
     uint32_t *fX = fwords ? (uint32_t *)calloc(fwords * 3, 4) : NULL;
-    if (fwords && !fX) { free(hX); return GECM_ERR_NOMEM; }
+    if (fwords && !fX) { free(hX); free_batch(c); return GECM_ERR_NOMEM; }
     int nt = host_threads();
     if ((size_t)nt > batch / 256 + 1) nt = (int)(batch / 256 + 1);
     build_job jobs[64];
@@ -562,7 +563,7 @@ int gecm_build_curves(gecm_ctx *c, const uint64_t *sigma, size_t batch)
         if (jobs[t].rc) rc = jobs[t].rc;
         anybad |= jobs[t].anybad;
     }
-    if (rc) { free(hX); free(fX); return rc; }
+    if (rc) { free(hX); free(fX); free_batch(c); return rc; }
     rc = gecm_dev_upload(c->dev, hX, hX + words, hX + 2 * words);
     if (!rc && fX) {
         rc = gecm_dev_upload(c->dev_f, fX, fX + fwords, fX + 2 * fwords);
@@ -570,7 +571,7 @@ int gecm_build_curves(gecm_ctx *c, const uint64_t *sigma, size_t batch)
     }
     free(hX);
     free(fX);
-    if (rc) { set_err("%s", gecm_dev_error()); return GECM_ERR_DEVICE; }
+    if (rc) { set_err("%s", gecm_dev_error()); free_batch(c); return GECM_ERR_DEVICE; }
     return anybad ? 1 : GECM_OK;
 }
 
@@ -582,13 +583,18 @@ int gecm_upload_points(gecm_ctx *c, const void *X, const void *Z, const void *s,
     int nl = c->nl;
     size_t words = (size_t)nl * batch;
     uint32_t *h = (uint32_t *)calloc(words * 3, 4);
-    if (!h) return GECM_ERR_NOMEM;
+    if (!h) { free_batch(c); return GECM_ERR_NOMEM; }
     const void *src[3] = {X, Z, s};
     for (int k = 0; k < 3; k++)
         for (size_t i = 0; i < batch; i++) {
             mpl_t v;
             vec_get(c, &v, src[k], batch, i);
-            if (mpl_cmp(&v, &c->N) >= 0) { free(h); set_err("gecm_upload_points: operand not < N"); return GECM_ERR_ARG; }
+            if (mpl_cmp(&v, &c->N) >= 0) {
+                free(h);
+                free_batch(c);                 /* the context holds no batch after a rejected upload */
+                set_err("gecm_upload_points: operand not < N");
+                return GECM_ERR_ARG;
+            }
             mpl_mulmod(&v, &v, &c->ref_to_int, &c->N);
             mpl_to_limbs32(h + (size_t)k * words + i, batch, nl, LIMB_BITS, &v);
         }
@@ -612,7 +618,7 @@ int gecm_upload_points(gecm_ctx *c, const void *X, const void *Z, const void *s,
         free(f);
     }
     free(h);
-    if (rc) { set_err("%s", gecm_dev_error()); return GECM_ERR_DEVICE; }
+    if (rc) { set_err("%s", gecm_dev_error()); free_batch(c); return GECM_ERR_DEVICE; }
     return GECM_OK;
 }
 
@@ -885,6 +891,12 @@ int gecm_stage2_init(gecm_ctx *c, uint32_t D, uint32_t U)
     if (!c || c->batch == 0 || c->B1 == 0) { set_err("gecm_stage2_init: run stage 1 first"); return GECM_ERR_STATE; }
     if (!D) D = gecm_s2_default_D(c->B1);
     if (!U) U = GECM_S2_DEFAULT_U;
+    /* the ring holds the 2L = 4U steps of the window plus one chunk being generated */
+    if (U > (S2_RING - S2_GIANT_CHUNK) / 4) {
+        set_err("gecm_stage2_init: U = %u is more than this build's giant-step ring takes (U <= %u)", U,
+                (S2_RING - S2_GIANT_CHUNK) / 4);
+        return GECM_ERR_ARG;
+    }
     if (c->s2.D != D || c->s2.U != U) {
         gecm_s2_plan_free(&c->s2);
         if (gecm_s2_plan_init(&c->s2, D, U)) { set_err("gecm_stage2_init: bad D/U"); return GECM_ERR_ARG; }
@@ -937,7 +949,18 @@ int gecm_stage2_pair(gecm_ctx *c, uint32_t steps, const uint32_t *pm_v, const ui
      * giant steps in chunks of S2_GIANT_CHUNK (one inversion each, csrc/gecm_stage2.hpp) into a ring, so
      * the tape carries ring slots and "generate n more" marks; the reference's counters (one batch
      * of 2U new steps and one inversion per window shift) are kept for the statistics. */
-    uint32_t *tape = (uint32_t *)malloc(((size_t)steps * 2 + 2 * ((size_t)steps / 16 + 64)) * sizeof(uint32_t));
+    /* The reference makes E = 2L + 2U * (window shifts) giant steps in this range and inverts them in batches:
+     * the first 2L together, then the 2U new ones of every shift (ecm.c:2425, 2499).  The device chunks never go
+     * beyond E, and the last chunk is exactly the reference's last batch [g0, E): when a curve's inversions fail
+     * (it found its factor already: every Z is 0 modulo it), the gcd the reference's accumulator ends up carrying
+     * is the one of its last failing batch (ecm.c:1925-1939 overwrites stg2acc each time), and the device's record
+     * (fe_inv_mont: the last failure wins) is then taken over the same points. */
+    uint64_t shifts = 0;
+    for (uint32_t i = 0; i < steps; i++) shifts += (pm_v[i] == 0 && pm_u[i] == 0);
+    const uint64_t E = 2ull * p->L + 2ull * p->U * shifts;
+    const uint64_t g0 = shifts ? E - 2ull * p->U : 0;
+    const size_t max_marks = (size_t)(E / S2_GIANT_CHUNK) + 4;
+    uint32_t *tape = (uint32_t *)malloc(((size_t)steps + max_marks) * 2 * sizeof(uint32_t));
     if (!tape) return GECM_ERR_NOMEM;
     size_t nt = 0;
     uint32_t run_amin = amin;
@@ -946,7 +969,9 @@ int gecm_stage2_pair(gecm_ctx *c, uint32_t steps, const uint32_t *pm_v, const ui
     const uint64_t base = 2ull * amin;           /* absolute number of giant step 0 (in units of D) */
 #define NEED(upto)                                                                                   \
     while (generated < (upto)) {                                                                     \
-        tape[nt++] = 0xffffffffu; tape[nt++] = S2_GIANT_CHUNK; generated += S2_GIANT_CHUNK; devinv++; \
+        const uint64_t lim = generated < g0 ? g0 : E;                                                \
+        const uint64_t n = lim - generated < S2_GIANT_CHUNK ? lim - generated : S2_GIANT_CHUNK;      \
+        tape[nt++] = 0xffffffffu; tape[nt++] = (uint32_t)n; generated += n; devinv++;                \
     }
     NEED(2ull * p->L);
     for (uint32_t i = 0; i < steps; i++) {

@@ -616,12 +616,14 @@ static void batch_invert(const orc_ctx *c, orc_work *w, const uint64_t *const *Z
     orc_mulmod(c, prefix[num - 1], one, B[num - 1]);          /* out of Montgomery form, :1903-1912 */
     fe_to_mpz(c, g, B[num - 1]);
     if (mpz_invert(inv, g, c->N) == 0) {                      /* :1925-1939 */
-        /* The reference stores gcd(product, N) into stg2acc and goes on with whatever its
-         * destination variable held (mpz_invert leaves it untouched; insert_mpz_to_vec of 0
-         * writes nothing, main.c:117-138), i.e. lane-order-dependent garbage.  Not restated:
-         * here the first such gcd is recorded and the inverse is taken as 0, which is what the
-         * product (csrc/gecm_stage2.hpp: fe_inv_mont) does too. */
-        if (!w->found_during_inv) mpz_gcd(w->inv_factor, g, c->N);
+        /* The reference stores gcd(product, N) into stg2acc — every time an inversion fails, so the LAST failing
+         * batch is the one whose gcd the accumulator carries to the end (each later cross product only multiplies
+         * it) — and goes on with whatever its destination variable held: GMP documents rop as undefined when
+         * mpz_invert fails; in practice it is the previous lane's inverse (lane-order-dependent garbage).  The
+         * garbage is not restated: the gcd of the last failing batch is recorded and reported as the factor, the
+         * inverse is taken as 0.  The reference's result differs from this only if one of the garbage cross
+         * products happens to vanish modulo another prime factor of N. */
+        mpz_gcd(w->inv_factor, g, c->N);
         w->found_during_inv = 1;
         mpz_set_ui(inv, 0);
     }

@@ -12,7 +12,12 @@ into oracle/_ref/).  The fixtures are data (inputs + outputs); no reference sour
   inputs.json : Cunningham-type command-line inputs -> the lines the reference prints while it
                 prepares N (main.c:393-527) and, for two of them, the save lines of a short run
 
-usage: python tests/golden/make_golden.py [--only stage1|l0|inputs] [--quick]
+  stage2_acc.json : (N, sigma0, B1, B2) -> work->stg2acc of all VECLEN lanes as the reference reads it at
+                ecm.c:1489, taken by oracle/ref_tap.c (the reference's ecm.c compiled with a tap on
+                extract_bignum_from_vec_to_mpz; `make -C oracle reftap`), plus the D the reference chose
+                (main.c:838-872) and its stage-2 counters
+
+usage: python tests/golden/make_golden.py [--only stage1|l0|inputs|stage2acc] [--quick]
 """
 import json, os, random, re, subprocess, sys, tempfile, hashlib
 
@@ -196,6 +201,41 @@ def gen_inputs():
     json.dump({"banner": banner, "runs": runs}, open(os.path.join(HERE, "inputs.json"), "w"), indent=1)
 
 
+def gen_stage2_acc():
+    """stg2acc of the reference itself for a few small (B1, B2): moduli without small factors (every inversion
+    succeeds, so the accumulator is a well-defined product), VECLEN curves on one thread."""
+    k1n = int([l for l in open("/root/reference/test.csh").read().splitlines() if "7372562557" in l][0].split()[1])
+    t35 = int(open("/root/reference/test_t35.csh").read().splitlines()[45].split()[1]) if os.path.exists("/root/reference/test_t35.csh") else k1n
+    cases = []
+    for name, digitbits, n, b1, b2, sigma0 in (("K1N_b1_2000_b2_1e5", 52, k1n, 2000, 100000, 100),
+                                               ("K1N_b1_5000_b2_3e5", 52, k1n, 5000, 300000, 200),
+                                               ("K1N_b1_3000_b2_150000", 52, k1n, 3000, 150000, 500),
+                                               ("T35N_b1_1000_b2_50000", 52, t35, 1000, 50000, 42),
+                                               ("K1N_d32_b1_300_b2_20000", 32, k1n, 300, 20000, 300)):
+        print("stage2acc:", name, flush=True)
+        exe = os.path.join(REFDIR, "avx-ecm-%d-tap" % digitbits)
+        veclen = 8 if digitbits == 52 else 16
+        with tempfile.TemporaryDirectory() as d:
+            tap = os.path.join(d, "tap.txt")
+            p = subprocess.run([exe, str(n), str(veclen), str(b1), "1", str(b2), str(sigma0)], cwd=d, capture_output=True,
+                               text=True, timeout=3600, env=dict(os.environ, GECM_TAP_FILE=tap))
+            rows = [l.split() for l in open(tap).read().splitlines()]
+            res = [l for l in open(os.path.join(d, "ecm_results.txt")).read().splitlines() if l.strip()] \
+                if os.path.exists(os.path.join(d, "ecm_results.txt")) else []
+        last = rows[-veclen:]
+        assert len({r[0] for r in last}) == 1 and [int(r[1]) for r in last] == list(range(veclen)), "tap tail is not stg2acc"
+        s2 = re.search(r"performed (\d+) pt-adds, (\d+) inversions, and (\d+) pair-muls", p.stdout)
+        w = re.search(r"w = (\d+), R = \d+, L = (\d+), U = (\d+)", p.stdout)
+        m = re.search(r"Choosing MAXBITS = (\d+), NWORDS = (\d+)", p.stdout)
+        cases.append({"name": name, "digitbits": digitbits, "N": str(n), "B1": b1, "B2": b2, "sigma0": sigma0,
+                      "curves": veclen, "maxbits": int(m.group(1)), "nwords": int(m.group(2)),
+                      "D": int(w.group(1)) if w else None, "L": int(w.group(2)) if w else None,
+                      "U": int(w.group(3)) if w else None,
+                      "stage2_counts": [int(x) for x in s2.groups()], "acc_hex": [r[2] for r in last],
+                      "results_lines": res})
+    json.dump(cases, open(os.path.join(HERE, "stage2_acc.json"), "w"), indent=1)
+
+
 if __name__ == "__main__":
     only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else None
     quick = "--quick" in sys.argv
@@ -205,3 +245,5 @@ if __name__ == "__main__":
         gen_stage1(quick)
     if only in (None, "inputs"):
         gen_inputs()
+    if only in (None, "stage2acc"):
+        gen_stage2_acc()

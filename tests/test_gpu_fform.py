@@ -135,8 +135,8 @@ def test_special_form_at_both_ends_of_every_limb_count(nl, k):
     assert out[0] == out[1] == out[2] == out[3]
 
 
-def test_small_batches_prefer_the_eight_lane_generic_kernel():
-    """left to itself (lanes = 0) a small batch of a 2^k - 1 cofactor runs the eight-lane generic kernel, a large
+def test_small_batches_prefer_the_many_lane_generic_kernel():
+    """left to itself (lanes = 0) a small batch of a 2^k - 1 cofactor runs the 32-lane generic kernel, a large
     one the special multiply; same save lines either way"""
     import pyecm
     n = (1 << 401) - 1
@@ -144,7 +144,7 @@ def test_small_batches_prefer_the_eight_lane_generic_kernel():
     assert eng.special_form() == (True, 401, 15)
     eng.build_curves(list(range(7000, 7032)))
     eng.stage1(400)
-    assert eng.lanes_per_curve() == 8 and not eng.special_form_used()
+    assert eng.lanes_per_curve() == 32 and not eng.special_form_used()
     small = eng.save_lines()
     eng.build_curves(list(range(7000, 7000 + 20000)))
     eng.stage1(400)

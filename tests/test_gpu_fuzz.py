@@ -1,6 +1,6 @@
 """Seeded differential fuzz on the GPU: random moduli (random odd N of 64..1030 bits, and Cunningham forms
 2^k -/+ 1 with random small cofactors removed), random B1 and sigma; every kernel flavour of stage 1 — one
-two and eight lanes per curve, generic and special-form multiply — must write the save lines of the oracle
+two, eight and 32 lanes per curve, generic and special-form multiply — must write the save lines of the oracle
 (oracle/ecm_oracle.c, itself pinned to the reference's outputs)."""
 import ctypes
 import os
@@ -61,7 +61,7 @@ def test_all_stage1_kernel_flavours_write_the_oracles_lines(orc, name, n, b1, si
     eng = pyecm.Engine(n, digitbits=digitbits)
     special_available = eng.special_form()[1] != 0
     for special in ((True, False) if special_available else (False,)):
-        for lanes in ((1, 2) if special else (1, 2, 8)):
+        for lanes in ((1, 2) if special else (1, 2, 8, 32)):
             eng.set_special_form(special)
             eng.set_lanes_per_curve(lanes)
             eng.build_curves(sig)

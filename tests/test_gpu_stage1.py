@@ -21,8 +21,9 @@ def _n_of(case):
 
 def _run(case, b1=None, lanes=1):
     """lanes: 1 = one curve per lane (the throughput kernel), 2 = X and Z of a curve on adjacent lanes, 8 = X and Z
-    on two quads of lanes with the limbs of each residue spread over the quad (what the library picks by itself
-    for batches this small) — include/gecm.h gecm_set_lanes_per_curve"""
+    on two quads of lanes with the limbs of each residue spread over the quad, 32 = X and Z on two DPP rows with
+    the limbs over the 16 lanes of a row (what the library picks by itself for batches this small) —
+    include/gecm.h gecm_set_lanes_per_curve"""
     import pyecm
     n = _n_of(case)
     eng = pyecm.Engine(n, digitbits=case["digitbits"])
@@ -43,7 +44,7 @@ SMALL = [c for c in CASES if c["B1"] <= 100000]
 BIG = [c for c in CASES if c["B1"] > 100000]
 
 
-@pytest.mark.parametrize("lanes", [1, 2, 8])
+@pytest.mark.parametrize("lanes", [1, 2, 8, 32])
 @pytest.mark.parametrize("case", SMALL, ids=[c["name"] for c in SMALL])
 def test_stage1_save_lines_small(case, lanes):
     lines, st, facs, cfg = _run(case, lanes=lanes)
@@ -77,6 +78,15 @@ def test_stage1_save_lines_b1_1e6_eight_lanes_per_curve(case):
     assert lines == case["save_lines"]
 
 
+BIG32 = [c for c in BIG if c["name"] in ("K1", "n415_b1_1000000", "n831_b1_1000000", "config1_fib791")]
+
+
+@pytest.mark.parametrize("case", BIG32, ids=[c["name"] for c in BIG32])
+def test_stage1_save_lines_b1_1e6_32_lanes_per_curve(case):
+    lines, st, facs, cfg = _run(case, lanes=32)
+    assert lines == case["save_lines"]
+
+
 def test_lanes_per_curve_is_chosen_from_the_batch_size():
     """auto mode: two lanes per curve unless the batch fills whole rounds of 2 wavefronts per SIMD (256 CUs)"""
     import pyecm
@@ -85,8 +95,12 @@ def test_lanes_per_curve_is_chosen_from_the_batch_size():
     assert eng.lanes_per_curve() == 0
     eng.build_curves(list(range(100, 116)))
     eng.stage1(500)
-    assert eng.lanes_per_curve() == 8                       # 16 curves: far below 32 curves per CU
+    assert eng.lanes_per_curve() == 32                      # 16 curves: far below 32 curves per CU
     small = [l.rstrip("\n") for l in eng.save_lines()]
+    eng.build_curves(list(range(100, 100 + 12000)))       # more than 32 curves per CU, not more than 64: 8 lanes each
+    eng.stage1(500)
+    assert eng.lanes_per_curve() == (8 if eng.cfg.dev_limbs >= 19 else 2)
+    assert [l.rstrip("\n") for l in eng.save_lines()[:16]] == small
     eng.build_curves(list(range(100, 100 + 20000)))       # too many for 8 lanes each, too few for whole rounds of 1
     eng.stage1(500)
     assert eng.lanes_per_curve() == 2
@@ -95,7 +109,7 @@ def test_lanes_per_curve_is_chosen_from_the_batch_size():
     eng.stage1(500)
     assert eng.lanes_per_curve() == 1
     assert [l.rstrip("\n") for l in eng.save_lines()[:16]] == small == case["save_lines"]
-    for bad in (3, 4, 16, -1):
+    for bad in (3, 4, 16, 64, -1):
         with pytest.raises(pyecm.GecmError):
             eng.set_lanes_per_curve(bad)
     eng.close()

@@ -1,8 +1,9 @@
 """GPU parity for stage 2 (ecm_stage2_init / ecm_stage2_pair, ecm.c:2201-2540) through the C ABI.
 
-  * accumulator (stg2acc) bit-identical to the oracle for the same (N, sigma, B1, B2, D, U): the
-    oracle itself is pinned to the reference by its counters and the factors it finds on the
-    reference's KATs (tests/test_oracle.py);
+  * accumulator (stg2acc) bit-identical to the REFERENCE's own work->stg2acc (tests/golden/stage2_acc.json, taken
+    from the reference at ecm.c:1489 by oracle/ref_tap.c) for the D, U the reference chose;
+  * accumulator bit-identical to the oracle for other (N, sigma, B1, B2, D, U): the oracle's stage 2 is pinned
+    to the same fixture and to the reference's result lines and counters by tests/test_oracle.py;
   * factors found on the reference's own stage-2 KATs (test.csh / test_t35.csh via
     tests/golden/stage1.json);
   * counters (point adds, inversions, pair multiplications) equal to the reference's printout.
@@ -68,6 +69,27 @@ def test_stage2_accumulator_equals_oracle(orc, b1, b2, D, U, digitbits):
         assert (st.ptadds, st.numinv, st.paired) == wcnt
 
 
+S2ACC = json.load(open(os.path.join(GOLDEN, "stage2_acc.json")))
+
+
+@pytest.mark.parametrize("case", S2ACC, ids=[c["name"] for c in S2ACC])
+def test_stage2_accumulator_equals_reference_stg2acc(case):
+    """every lane of the reference's stg2acc (ecm.c:1489; CROSS_PRODUCT_INV ecm.c:1857-1859), with the library
+    left to choose D and U as the reference does (main.c:838-872; U = 16), and the reference's counters"""
+    import pyecm
+    eng = pyecm.Engine(int(case["N"]), digitbits=case["digitbits"])
+    assert eng.cfg.nwords == case["nwords"]
+    eng.build_curves([case["sigma0"] + k for k in range(case["curves"])])
+    eng.stage1(case["B1"])
+    eng.stage2(case["B2"])
+    st = eng.stage2_stats()
+    assert (st.D, st.U, st.L) == (case["D"], case["U"], case["L"])
+    assert [st.ptadds, st.numinv, st.paired] == case["stage2_counts"]
+    assert eng.download_acc() == [int(h, 16) for h in case["acc_hex"]]
+    assert all(eng.stage2_factor(k) is None for k in range(case["curves"]))
+    eng.close()
+
+
 def test_stage2_phase_api_matches_convenience(orc):
     """gecm_stage2_init + gecm_pair_primes + gecm_stage2_pair (the reference's own call sequence)"""
     import pyecm
@@ -123,6 +145,23 @@ def test_stage2_when_stage1_already_found_the_factor():
     """random N with small factors: Z == 0 mod p after stage 1, so the batch inversion of stage 2
     meets a non-invertible product (ecm.c:1927-1939); the factor is reported from that gcd"""
     _kat("n415_b1_10000_b2_1e6", lanes=8)
+
+
+def test_stage2_config1_lane_with_stage1_factor():
+    """BASELINE configs[0] (fib(791)/13/677/216416017, 8 curves, B2 = 1e8): sigma 1007 finds its PRP21 in stage 1
+    and the reference reports it again after stage 2; no other lane reports anything"""
+    _kat("config1_fib791", lanes=8)
+
+
+def test_stage2_rejects_table_height_beyond_the_ring():
+    import pyecm
+    eng = pyecm.Engine(K1N)
+    eng.build_curves([100, 101])
+    eng.stage1(300)
+    with pytest.raises(pyecm.GecmError):
+        eng.stage2_init(210, 129)              # window of 4U giant steps + one chunk would not fit the ring
+    eng.stage2_init(210, 128)
+    eng.close()
 
 
 def test_device_factor_scan_equals_per_curve_host_gcd():

@@ -105,3 +105,62 @@ def test_oracle_prac_choice_is_deterministic(orc):
     # spot values; the full chain is pinned by the save lines above
     assert orc.orc_prac_choice(3) in range(10)
     assert orc.orc_lucas_cost(7, 0.61803398874989485) > 0
+
+
+# ---- stage 2 (ecm_stage2_init ecm.c:2201-2340, pair ecm.c:2559-2910, ecm_stage2_pair ecm.c:2342-2540) ----
+S2ACC = json.load(open(os.path.join(GOLDEN, "stage2_acc.json")))
+
+
+def _orc_stage2(orc, c, sigma, b1, b2, D, U=16):
+    acc = ctypes.create_string_buffer(4096)
+    fac = ctypes.create_string_buffer(2048)
+    cnt = (ctypes.c_uint64 * 3)()
+    orc.orc_stage2(c, sigma, b1, b2, D, U, acc, fac, len(fac), cnt)
+    return int(acc.value, 16), (int(fac.value) if fac.value else None), list(cnt)
+
+
+@pytest.mark.parametrize("case", S2ACC, ids=[c["name"] for c in S2ACC])
+def test_oracle_stage2_accumulator_against_reference(orc, case):
+    """work->stg2acc as the reference itself holds it at ecm.c:1489 (tests/golden/stage2_acc.json, taken from the
+    reference by oracle/ref_tap.c): every lane bit for bit, with the D, U and counters the reference printed"""
+    c = orc.orc_create(case["N"].encode(), case["digitbits"])
+    assert orc.orc_nwords(c) == case["nwords"]
+    for lane, want in enumerate(case["acc_hex"]):
+        acc, fac, cnt = _orc_stage2(orc, c, case["sigma0"] + lane, case["B1"], case["B2"], case["D"], case["U"])
+        assert acc == int(want, 16), (case["name"], lane)
+        assert cnt == case["stage2_counts"] and fac is None
+    orc.orc_destroy(c)
+
+
+def _wheel(b1):
+    """main.c:838-872"""
+    for lim, d in ((60, 30), (128, 60), (256, 120), (512, 210), (2048, 385), (4096, 1155)):
+        if b1 <= lim:
+            return d
+    return 2310
+
+
+def _stage2_lines(case):
+    want = {}
+    for l in case["results_lines"]:
+        m = re.match(r"found (?:PRP|C)\d+ factor (\d+) in stage 2 .*vec (\d+), sigma (\d+)", l)
+        if m:
+            want[int(m.group(3))] = int(m.group(1))
+    return want
+
+
+@pytest.mark.parametrize("name,lanes", [("n415_b1_10000_b2_1e6", range(8)), ("T35_46", [0]), ("K2", [0]),
+                                        ("config1_fib791", [7])])
+def test_oracle_stage2_result_lines_and_counters(orc, name, lanes):
+    """the reference's stage-2 KATs (test_t35.csh:46, test.csh:7 over two prime ranges) and the lanes on which stage 1
+    had already found the factor, so that stage 2's batch inversions meet a non-invertible product
+    (ecm.c:1925-1939): same factor per lane as the reference's ecm_results.txt lines, same printed counters"""
+    case = next(c for c in S1 if c["name"] == name)
+    want = _stage2_lines(case)
+    c = orc.orc_create(str(_n_of(case)).encode(), case["digitbits"])
+    for lane in lanes:
+        sigma = int(case["save_lines"][lane].split("SIGMA=")[1].split(";")[0])
+        acc, fac, cnt = _orc_stage2(orc, c, sigma, case["B1"], case["B2"], _wheel(case["B1"]))
+        assert fac == want.get(sigma), (name, lane, sigma)
+        assert cnt == case["stage2_counts"]
+    orc.orc_destroy(c)
