@@ -73,22 +73,27 @@ def test_tiny_bounds_and_b1_change():
 
 def test_rejected_batch_leaves_no_batch_behind():
     """an input error in gecm_build_curves / gecm_upload_points must not leave the context claiming a batch
-    nothing was uploaded for: the phase functions then answer GECM_ERR_STATE (-4)"""
+    nothing was uploaded for: either the previous batch is untouched (inputs refused before anything is
+    allocated) or the context holds no batch and the phase functions answer GECM_ERR_STATE (-4)"""
     import pyecm
     L = pyecm.lib
     n = ((1 << 127) - 1) * ((1 << 107) - 1)
     eng = pyecm.Engine(n)
     eng.build_curves([11, 12, 13])
     eng.stage1(50)
+    before = eng.save_lines()
     with pytest.raises(pyecm.GecmError, match="sigma"):
-        eng.build_curves([11, 5, 13])                      # sigma < 6 (ecm.c:1564-1570 redraws; the ABI refuses)
-    assert L.gecm_stage1(eng._h, 50) == -4
+        eng.build_curves([11, 5, 13, 14])                  # sigma < 6 (ecm.c:1564-1570 redraws; the ABI refuses)
+    eng.batch = 3
+    assert eng.save_lines() == before                      # refused before the batch was replaced
     buf = ctypes.create_string_buffer(4096)
-    assert L.gecm_format_save_line(eng._h, 0, buf, len(buf)) < 0
-    eng.build_curves([11, 12, 13])
-    eng.stage1(50)                                         # and the context is usable again
+    assert L.gecm_format_save_line(eng._h, 3, buf, len(buf)) < 0
     one = eng.pack([1, 1])
     big = eng.pack([n, 1])                                 # operand not < N
     assert L.gecm_upload_points(eng._h, big, one, one, 2) == -2
-    assert L.gecm_stage1(eng._h, 50) == -4
+    assert L.gecm_stage1(eng._h, 50) == -4                 # refused after the old batch was dropped: no batch now
+    assert L.gecm_format_save_line(eng._h, 0, buf, len(buf)) < 0
+    eng.build_curves([11, 12, 13])
+    eng.stage1(50)                                         # and the context is usable again
+    assert eng.save_lines() == before
     eng.close()
