@@ -1,10 +1,16 @@
 /* avx_ecm_main.c — the avx-ecm command line on top of libgecm.
  *
- *     avx-ecm input curves B1 [gpus] [B2] [sigma]
+ *     avx-ecm input curves B1 [threads] [B2] [sigma]
  *
- * Same positional arguments as the reference (main.c:380-384, 459-460, 537-559); the 4th argument,
- * "threads" there, is the number of GPUs here (the thread pool is replaced by one host thread per
- * GPU, each owning one gecm_ctx).  Reproduces vececm's sequence (ecm.c:1077-1544) and its
+ * Same positional arguments as the reference (main.c:380-384, 459-460, 537-559).  The 4th argument keeps the
+ * reference's meaning for everything an existing script can observe: it only enters the rounding of the curve
+ * count (main.c:585-589: curves per thread, whole 8-lane vectors per thread) and the banner.  It does NOT select
+ * GPUs: the run uses every visible HIP device (or the first GECM_GPUS of them), one host thread and one gecm_ctx
+ * per GPU, and the result files do not depend on how many there are.  One deliberate difference: with a fixed
+ * sigma and more than one thread the reference gives every thread the SAME eight sigmas per step (ecm.c:1187 adds
+ * the step to thread 0's sigmas for all threads), i.e. it runs every curve `threads` times; here curve k of the run
+ * gets sigma + k, which for threads = 1 is exactly the reference's assignment.
+ * Reproduces vececm's sequence (ecm.c:1077-1544) and its
  * observable protocol: the banner lines, "Stage 1 completed at prime ..." counters, the factor
  * lines on stdout and in ecm_results.txt (ecm.c:1356-1367, 1510-1522) and the GMP-ECM resume
  * lines appended to save_b1.txt (ecm.c:1372-1380), in global curve order (sigma ascending), so the
@@ -55,6 +61,7 @@ typedef struct {
     int rc;
     char err[512];
     double t_build, t_stage1, t_s2;
+    const gecm_pairs *pm;      /* the pair map of the current prime range (made once, shared) */
 } job_t;
 
 static void *job_build(void *p)
@@ -87,10 +94,23 @@ static void *job_stage2(void *p)
     double t = now();
     j->rc = 0;
     if (j->ncurves) {
-        j->rc = gecm_stage2(j->ctx, j->B2, 0, 0);
+        j->rc = gecm_stage2_init(j->ctx, 0, 0);                       /* ecm.c:1401-1407 */
+        if (j->rc == 0) j->rc = gecm_sync(j->ctx);
         if (j->rc < 0) snprintf(j->err, sizeof j->err, "%s", gecm_last_error());
     }
     j->t_s2 = now() - t;
+    return NULL;
+}
+
+static void *job_stage2_pair(void *p)
+{
+    job_t *j = (job_t *)p;
+    j->rc = 0;
+    if (j->ncurves) {
+        j->rc = gecm_stage2_pair(j->ctx, j->pm->steps, j->pm->pairmap_v, j->pm->pairmap_u, j->pm->amin);   /* ecm.c:1460 */
+        if (j->rc == 0) j->rc = gecm_sync(j->ctx);
+        if (j->rc < 0) snprintf(j->err, sizeof j->err, "%s", gecm_last_error());
+    }
     return NULL;
 }
 
@@ -111,7 +131,7 @@ static int run_all(job_t *jobs, int n, void *(*fn)(void *))
 int main(int argc, char **argv)
 {
     if (argc < 4) {
-        printf("usage: avx-ecm $input $numcurves $B1 [$gpus] [$B2] [$sigma]\n");   /* main.c:382 */
+        printf("usage: avx-ecm $input $numcurves $B1 [$threads] [$B2] [$sigma]\n");   /* main.c:382 */
         return 1;
     }
     double t_start = now();
@@ -127,21 +147,24 @@ int main(int argc, char **argv)
     size_t numcurves = strtoul(argv[2], NULL, 10);
     uint64_t B1 = strtoull(argv[3], NULL, 10);
     uint64_t B2 = 100ULL * B1;                                                    /* main.c:462 */
-    int gpus = 1, do_stage2 = 1;
+    int threads = 1, do_stage2 = 1;
     uint64_t sigma0 = 0;
-    if (argc > 4) gpus = atoi(argv[4]);
+    if (argc > 4) threads = atoi(argv[4]);
     if (argc > 5) B2 = strtoull(argv[5], NULL, 10);
     if (argc > 6) sigma0 = strtoull(argv[6], NULL, 10);
-    if (B2 <= B1) do_stage2 = 0;                                                  /* main.c:548-552 */
+    if (B2 <= B1) { do_stage2 = 0; B2 = B1; }                                      /* main.c:548-552 */
+    if (threads < 1) threads = 1;
     int have = gecm_device_count();
     if (have < 1) { fprintf(stderr, "no HIP device visible\n"); return 2; }
-    if (gpus < 1) gpus = 1;
-    if (gpus > have) gpus = have;
+    int gpus = have;
+    if (getenv("GECM_GPUS") && atoi(getenv("GECM_GPUS")) > 0 && atoi(getenv("GECM_GPUS")) < gpus) gpus = atoi(getenv("GECM_GPUS"));
     if (gpus > MAX_GPUS) gpus = MAX_GPUS;
     if (numcurves == 0 || B1 < 2 || B1 > 100000000ULL) { printf("need curves >= 1 and 2 <= B1 <= 1e8\n"); return 1; }
-    /* the reference runs whole vectors: curves are rounded up to a multiple of VECLEN = 8
-     * (main.c:585-589, ecm.c:1151), so "10 curves" writes 16 resume lines there and here */
-    numcurves = (numcurves + 7) / 8 * 8;
+    /* main.c:585-589: at least one curve per thread, the same number on every thread; ecm.c:1151: every thread
+     * runs whole vectors of VECLEN = 8, so "10 curves" on one thread writes 16 resume lines there and here */
+    if (numcurves < (size_t)threads) numcurves = (size_t)threads;
+    const size_t per_thread = numcurves / (size_t)threads + (numcurves % (size_t)threads != 0);
+    numcurves = (per_thread + 7) / 8 * 8 * (size_t)threads;
 
     fputs(prep_log, stdout);          /* "gen: ...", "removing algebraic ...", "commencing parallel ecm on ..." */
     job_t jobs[MAX_GPUS];
@@ -154,11 +177,13 @@ int main(int argc, char **argv)
     gecm_get_config(jobs[0].ctx, &cfg);
     char devname[256];
     gecm_device_name(jobs[0].ctx, devname, sizeof devname);
-    /* main.c:529-533; the GPU limb layout replaces VECLEN */
-    printf("ECM has been configured with DIGITBITS = %d, device limbs = %d x 28 bits, %d GPU(s): %s\n",
-           cfg.digitbits, cfg.dev_limbs, gpus, devname);
+    /* main.c:529-533, verbatim: DIGITBITS and VECLEN describe the vector format at the boundary (curves come in
+     * groups of 8, limbs of 52 bits); the device's own numbers follow on a line of their own */
+    printf("ECM has been configured with DIGITBITS = %d, VECLEN = %d, GMP_LIMB_BITS = %d\n", cfg.digitbits, 8, 64);
     printf("Choosing MAXBITS = %d, NWORDS = %d, NBLOCKS = %d based on input size %d\n", cfg.maxbits, cfg.nwords,
            cfg.nwords / 4, cfg.nbits);
+    printf("%s: %d GPU(s) [%s], residues of %d limbs x 28 bits on the device\n", gecm_version(), gpus, devname,
+           cfg.dev_limbs);
     if (inf.ref_special_reduction) {
         /* main.c:644-670 prints "Using special Mersenne mod for factor of: 2^k-1" here */
         int fk = 0, fl = 0;
@@ -170,10 +195,10 @@ int main(int argc, char **argv)
             printf("Input divides 2^%d %c %d: running REDC on the %d-bit cofactor (residues = the reference's modulo N)\n",
                    inf.k, inf.form > 0 ? '-' : '+', inf.form, inf.nbits);
     }
-    if (sigma0) printf("starting with sigma = %lu\n", (unsigned long)sigma0);     /* main.c:558 */
+    if (argc > 6) printf("starting with sigma = %lu\n", (unsigned long)sigma0);   /* main.c:558 */
     size_t per_pass = (size_t)FULL_BATCH * (size_t)gpus;
-    printf("Input has %d bits, using %d GPU(s) (%zu curves/pass)\n", cfg.nbits, gpus,
-           numcurves < per_pass ? numcurves : per_pass);                          /* main.c:591-592 */
+    printf("Input has %d bits, using %d threads (%d curves/thread)\n", cfg.nbits, threads, (int)per_thread);   /* main.c:591-592 */
+    printf("Processing in batches of %u primes\n", 100000000u);                  /* main.c:593 */
     printf("Initialization took %1.4f seconds.\n", now() - t_start);              /* main.c:776 */
 
     uint64_t lcg = (uint64_t)(t_start * 1e6) * 0x9E3779B97F4A7C15ULL + (uint64_t)getpid();
@@ -239,10 +264,31 @@ int main(int argc, char **argv)
         fflush(stdout);
         if (do_stage2) {                                                         /* ecm.c:1394-1528 */
             t = now();
-            if (run_all(jobs, gpus, job_stage2)) return 2;
+            if (run_all(jobs, gpus, job_stage2)) return 2;                       /* stage-2 init, ecm.c:1401-1421 */
+            printf("Stage 2 Init took %1.4f seconds\n", now() - t);              /* ecm.c:1421 */
             gecm_stage2_stats s2;
             gecm_get_stage2_stats(jobs[0].ctx, &s2);
-            printf("\nw = %u, L = %u, U = %u, umax = %u\nlast amin: %u\n", s2.D, s2.L, s2.U, s2.U * s2.D, s2.amin_last);
+            uint32_t rcount = 0;
+            for (uint32_t i = 0; i < 2 * s2.D; i++) {                            /* main.c:874-882: R - 3 */
+                uint32_t a = i, b = 2 * s2.D;
+                while (b) { uint32_t r = a % b; a = b; b = r; }
+                rcount += a == 1;
+            }
+            for (uint64_t p = B1; p < B2; p += 100000000ULL) {                   /* ecm.c:1424-1476 */
+                const uint64_t hi = p + 100000000ULL < B2 ? p + 100000000ULL : B2;
+                gecm_pairs pm;
+                printf("commencing pair on range %lu:%lu\n", (unsigned long)p, (unsigned long)hi);   /* ecm.c:2568 */
+                if (gecm_pair_primes(&pm, p, hi, s2.D, s2.U)) { fprintf(stderr, "%s\n", gecm_last_error()); return 2; }
+                printf("%u pairs found from %u primes (ratio = %1.2f)\n", pm.pairs, pm.primes,
+                       pm.primes ? (double)pm.pairs / (double)pm.primes : 0.0);   /* ecm.c:2904-2905 */
+                printf("\ncommencing stage 2 at A=%lu\nw = %u, R = %u, L = %u, U = %d, umax = %u, amin = %u\n",
+                       2ul * (unsigned long)pm.amin * s2.D, s2.D, rcount, s2.L, (int)s2.U, s2.U * s2.D, pm.amin);   /* ecm.c:2440-2442 */
+                for (int g = 0; g < gpus; g++) jobs[g].pm = &pm;
+                if (run_all(jobs, gpus, job_stage2_pair)) return 2;
+                gecm_pairmap_release(&pm);
+                gecm_get_stage2_stats(jobs[0].ctx, &s2);
+                printf("\nlast amin: %u\n", s2.amin_last);                       /* ecm.c:1462 */
+            }
             printf("\nStage 2 took %1.4f seconds\n", now() - t);                 /* ecm.c:1481 */
             printf("performed %lu pt-adds, %lu inversions, and %lu pair-muls in stage 2\n",
                    (unsigned long)s2.ptadds, (unsigned long)s2.numinv, (unsigned long)s2.paired);   /* ecm.c:1482 */

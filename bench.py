@@ -48,7 +48,14 @@ sys.path.insert(0, os.path.join(ROOT, "avx-ecm_amd"))
 
 PEAK_MAD_PER_S = 256 * 4 * 16 * 2.4e9      # CUs x SIMDs x lanes/clk (v_mad_u64_u32: 4 clk per wave64) x Hz
 PEAK_FMA64_PER_S = 256 * 4 * 16 * 2.4e9    # v_fma_f64 issues at the same rate (78.6 TFLOP/s datasheet)
-KERNEL_NAMES = {1: "k_stage1<%d>", 2: "k_stage1_pair<%d>", 8: "k_stage1_quad<%d>", 32: "k_stage1_row<%d>"}
+KERNEL_NAMES = {1: "k_stage1<%d>", 2: "k_stage1_pair<%d>", 8: "k_stage1_quad<%d>"}
+
+
+def kernel_name(lanes, dev_limbs):
+    """the stage-1 kernel a launch with this layout runs, as rocprofv3 prints it"""
+    if lanes == 32:        # templated on limbs per lane (16 lanes per residue, one limb more than the buffers hold)
+        return "k_stage1_row<%d, false>" % ((dev_limbs + 1 + 15) // 16)
+    return KERNEL_NAMES.get(lanes, "k_stage1_l%d<%%d>" % lanes) % dev_limbs
 
 
 def work_per_curve(ptadds, ptdups, nl, n52):
@@ -308,7 +315,7 @@ def main():
     st = eng.stage1_stats()
     cfg = eng.cfg
     lanes = eng.lanes_per_curve()
-    kname = KERNEL_NAMES.get(lanes, "k_stage1_l%d<%%d>" % lanes) % cfg.dev_limbs
+    kname = kernel_name(lanes, cfg.dev_limbs)
 
     stage2 = None
     if a.b2 > a.b1 and not a.no_engine:

@@ -16,9 +16,10 @@ EXE = os.path.join(ROOT, "avx-ecm_amd", "avx-ecm")
 S1 = {c["name"]: c for c in json.load(open(os.path.join(GOLDEN, "stage1.json")))}
 
 
-def _run(args):
+def _run(args, env=None):
     with tempfile.TemporaryDirectory() as d:
-        p = subprocess.run([EXE] + [str(a) for a in args], cwd=d, capture_output=True, text=True, timeout=900)
+        p = subprocess.run([EXE] + [str(a) for a in args], cwd=d, capture_output=True, text=True, timeout=900,
+                           env=dict(os.environ, **(env or {})))
         assert p.returncode == 0, p.stdout + p.stderr
         save = open(os.path.join(d, "save_b1.txt")).read() if os.path.exists(os.path.join(d, "save_b1.txt")) else ""
         res = open(os.path.join(d, "ecm_results.txt")).read() if os.path.exists(os.path.join(d, "ecm_results.txt")) else ""
@@ -78,3 +79,42 @@ def test_cli_more_curves_than_one_pass():
     eng.stage1(b1)
     assert [l.rstrip("\n") for l in eng.save_lines()] == [lines[k] for k in pick]
     eng.close()
+
+
+def test_cli_prints_the_reference_banner_lines():
+    """main.c:529-533, 558, 591-593 and the stage-2 lines of ecm.c:2440-2442, 2568, 2904-2905, 1421, 1462, 1481-1483,
+    verbatim (values as the reference printed them for this command: tests/golden/cli_stdout.json)"""
+    want = json.load(open(os.path.join(GOLDEN, "cli_stdout.json")))
+    out, save, res = _run(want["args"])
+    import re
+    norm = lambda l: re.sub(r"[0-9]+\.[0-9]+ seconds", "T seconds", l)
+    got = [norm(l) for l in out.splitlines()]
+    for l in want["lines"]:
+        assert norm(l) in got, l
+
+
+def test_cli_fourth_argument_is_the_reference_s_thread_count():
+    """argv[4] is `threads` as in the reference: it rounds the curve count (main.c:585-589: per thread, whole vectors
+    of 8) and is printed; it neither selects GPUs nor fails when it exceeds them.  Curve k gets sigma + k."""
+    c = S1["K1N_two_full_batches_b1_500"]
+    out, save, res = _run([c["N"], 20, c["B1"], 16, c["B2"], c["sigma0"]])
+    assert "using 16 threads (2 curves/thread)" in out
+    lines = save.splitlines()
+    assert len(lines) == 16 * 8                                       # 2 curves per thread -> one vector of 8 each
+    assert [int(l.split("SIGMA=")[1].split(";")[0]) for l in lines] == list(range(c["sigma0"], c["sigma0"] + 128))
+    assert lines[:16] == c["save_lines"]                              # the reference's own lines for sigma0 .. +15
+
+
+def test_cli_two_gpus_write_the_same_files():
+    """one host thread and one context per GPU (GECM_GPUS caps how many are used): save_b1.txt and ecm_results.txt
+    do not depend on the number of GPUs.  Skipped on a one-GPU box."""
+    import pyecm
+    if pyecm.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    c = S1["n415_b1_10000_b2_1e6"]
+    one = _run([c["N"], 64, c["B1"], 1, c["B2"], c["sigma0"]], env={"GECM_GPUS": "1"})
+    two = _run([c["N"], 64, c["B1"], 1, c["B2"], c["sigma0"]], env={"GECM_GPUS": "2"})
+    assert "2 GPU(s)" in two[0] and "1 GPU(s)" in one[0]
+    assert one[1] == two[1] and len(one[1].splitlines()) == 64
+    strip = lambda ls: [__import__("re").sub(r"thread \d+, vec \d+", "", l) for l in ls]
+    assert strip(one[2]) == strip(two[2])
