@@ -45,7 +45,7 @@ int gecm_dev_set_rowconst(gecm_dev *d, int nq, const uint32_t *words);
 /* F-form (modulus 2^k - 1, csrc/gecm_field.hpp): number of top limbs the kernel for `nl` limbs reads from
  * the modulus (all limbs below must be 2^28 - 1), and the switch that makes gecm_dev_stage1 use it. */
 int gecm_dev_fform_generic_limbs(int nl);
-void gecm_dev_set_fform(gecm_dev *d, int form);   /* +1: 2^k - 1, -1: 2^k + 1, 0: off */
+void gecm_dev_set_fform(gecm_dev *d, int form);   /* +1: 2^k - 1, -1: 2^k + 1, 2: 2^k - c (limbs 0, 1 below F), 0: off */
 int gecm_dev_last_lanes(gecm_dev *d);
 int gecm_dev_sync(gecm_dev *d);
 float gecm_dev_last_kernel_ms(gecm_dev *d);

@@ -55,7 +55,7 @@ struct gecm_dev {
     uint32_t *dModQ = nullptr;   // N and K' limbs padded to 40 each, for the eight-lane kernel
     uint32_t *dRowC = nullptr;   // constants of the 32-lane kernel (gecm_dev_set_rowconst), GECM_ROW_KINDS x GECM_ROW_WORDS
     int row_nq = 0;              // limbs per lane there; 0 = not available
-    int fform = 0;        // +1 / -1: modulus is 2^k - 1 / 2^k + 1 and stage 1 uses the special multiply (gecm_dev_set_fform)
+    int fform = 0;        // +1 / -1 / 2: modulus is 2^k - 1 / 2^k + 1 / 2^k - c and stage 1 uses the special multiply (gecm_dev_set_fform)
     int cus = 0;          // compute units of the device (4 SIMDs each)
     int last_lanes = 0;   // lanes per curve the last stage-1 launch used
 };
@@ -297,7 +297,7 @@ extern "C" int gecm_dev_fform_generic_limbs(int nl)
     return -1;
 }
 
-extern "C" void gecm_dev_set_fform(gecm_dev *d, int form) { d->fform = form > 0 ? 1 : form < 0 ? -1 : 0; }
+extern "C" void gecm_dev_set_fform(gecm_dev *d, int form) { d->fform = form == 2 ? 2 : form > 0 ? 1 : form < 0 ? -1 : 0; }
 
 extern "C" int gecm_dev_stage1(gecm_dev *d, int lanes_per_curve)
 {

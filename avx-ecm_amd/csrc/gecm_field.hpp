@@ -381,6 +381,92 @@ __device__ __forceinline__ void fe_sqr(Fe<NL> &r, const Fe<NL> &a, const ModF<NL
     r = o;
 }
 
+// ---- moduli of the form 2^k - c, c odd, 1 < c < 2^52 ("C-form": the reference's pseudo-Mersenne inputs, main.c:432-441,
+// for which it folds with vecmulmod52_mersenne, vecarith52.c:284-1031) ------------------------------------------------
+// Mw = 2^k - c = (2^k - 1) - (c - 1): in 28-bit limbs the F-form modulus with e0 = (c-1) mod 2^28 taken off limb 0 and
+// e1 = (c-1) >> 28 off limb 1 (no borrow: e < 2^28), so in the REDC half of column C
+//     sum_i q_i n_(C-i) = [the F-form sum] - e0 * q_C - e1 * q_(C-1),
+// and rho = -Mw^-1 = (c mod 2^28)^-1 mod 2^28 is a real multiplier.  Per column that is, on top of the F-form's class
+// sums: one v_mul_lo for the digit, one multiply-add q_C * n_0 (n_0 = F - e0, read from the modulus) instead of the
+// F-form's "+ q", and one signed multiply-add -e1 * q_(C-1).  Same REDC, same digits, same integers as the generic
+// multiply for this modulus; the host reduces modulo N when the points come back.
+template <int NL>
+struct ModC : ModK<NL> {};
+
+__device__ __forceinline__ void mad_neg(uint64_t &acc, uint32_t e, uint32_t q)      // acc -= e * q   (e < 2^28, q < 2^28)
+{
+    const int32_t ne = -(int32_t)e;
+    asm("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(ne), "v"(q) : "vcc");
+}
+
+// REDC part of column C before the digit: the F-form part with the digits paired with limbs 1 .. NF-1 (limb 0's
+// partner is the digit of this column, added by the caller), then the correction for limb 1.
+template <int C, int NL>
+__device__ __forceinline__ void redc_c_col(uint64_t &acc, FSums<NL> &T, const uint32_t (&q)[NL], const uint32_t (&n)[NL], uint32_t e1)
+{
+    redc_f_col<C>(acc, T, q, n);
+    if constexpr (C >= 1 && C - 1 <= NL - 1) mad_neg(acc, e1, q[C - 1]);
+}
+
+template <int NL, bool SQR>
+__device__ __forceinline__ void fe_mulsqr_c(Fe<NL> &r, const Fe<NL> &a, const Fe<NL> &b, const ModC<NL> &m)
+{
+    static_assert(FPolicy<NL>::NF >= 3, "limbs 0, 1 carry the c - 1 correction; at least one pure F limb above them");
+    uint32_t q[NL];
+    uint32_t a2[NL];
+    Fe<NL> o;
+    if constexpr (SQR) {
+#pragma unroll
+        for (int i = 0; i < NL; i++) a2[i] = a.v[i] << 1;
+    }
+    const uint32_t e1 = GECM_LIMB_MASK - m.n[1];
+    uint32_t n0[1] = {m.n[0]};
+    uint64_t acc = 0;
+    FSums<NL> T;
+#pragma unroll
+    for (int j = 0; j < FPolicy<NL>::NC; j++) T.t[j] = 0;
+    static_for<0, NL>([&](auto ic) {
+        constexpr int c = decltype(ic)::value;
+        if constexpr (SQR) {
+            col_vv<c, 0, (c + 1) / 2>(acc, a.v, a2);
+            if constexpr ((c & 1) == 0) col_vv<c, c / 2, c / 2 + 1>(acc, a.v, a.v);
+        } else {
+            col_vv<c, 0, c + 1>(acc, a.v, b.v);
+        }
+        redc_c_col<c>(acc, T, q, m.n, e1);
+        q[c] = ((uint32_t)acc * m.rho) & GECM_LIMB_MASK;
+        uint32_t qc[1] = {q[c]};
+        mad_chain_s<1>(acc, qc, n0);                            // + q_c * n_0: the column is now 0 mod 2^28
+        acc >>= GECM_LIMB_BITS;
+        T.t[c % FPolicy<NL>::NC] += q[c];
+    });
+    static_for<NL, 2 * NL>([&](auto ic) {
+        constexpr int c = decltype(ic)::value;
+        if constexpr (SQR) {
+            col_vv<c, c - NL + 1, (c + 1) / 2>(acc, a.v, a2);
+            if constexpr ((c & 1) == 0 && c / 2 < NL) col_vv<c, c / 2, c / 2 + 1>(acc, a.v, a.v);
+        } else {
+            col_vv<c, c - NL + 1, NL>(acc, a.v, b.v);
+        }
+        redc_c_col<c>(acc, T, q, m.n, e1);
+        o.v[c - NL] = (c == 2 * NL - 1) ? (uint32_t)acc : ((uint32_t)acc & GECM_LIMB_MASK);
+        acc >>= GECM_LIMB_BITS;
+    });
+    r = o;
+}
+
+template <int NL>
+__device__ __forceinline__ void fe_mul(Fe<NL> &r, const Fe<NL> &a, const Fe<NL> &b, const ModC<NL> &m)
+{
+    fe_mulsqr_c<NL, false>(r, a, b, m);
+}
+
+template <int NL>
+__device__ __forceinline__ void fe_sqr(Fe<NL> &r, const Fe<NL> &a, const ModC<NL> &m)
+{
+    fe_mulsqr_c<NL, true>(r, a, a, m);
+}
+
 // ---- moduli of the form 2^k + 1 ("P-form") ---------------------------------------------------
 // Mw = 2^k + 1 in 28-bit limbs is 1, 0, ..., 0 below the limb that holds bit k, and rho = -Mw^-1 mod 2^28
 // = 2^28 - 1.  The REDC half of a column is then: the digit q_c = (-acc) mod 2^28, its product with limb 0

@@ -56,7 +56,7 @@ struct ModArgsS {
     Fe<NL> one;
 };
 
-// MOD = ModF<NL> (2^k - 1) or ModP<NL> (2^k + 1)
+// MOD = ModF<NL> (2^k - 1), ModP<NL> (2^k + 1) or ModC<NL> (2^k - c)
 template <int NL, class MOD>
 __global__ void __launch_bounds__(64, 2)
 k_stage1_f(const uint32_t *__restrict__ tape, uint32_t tape_len, uint32_t *__restrict__ X,
@@ -325,12 +325,14 @@ static void launch_stage1_special(void *stream, const gecm_modconst *mc, const u
                            tape, tape_len, X, Z, S, stride, a);
 }
 
-/* form: +1 = modulus 2^k - 1 (F-form), -1 = modulus 2^k + 1 (P-form) */
+/* form: +1 = modulus 2^k - 1 (F-form), -1 = modulus 2^k + 1 (P-form), 2 = modulus 2^k - c (C-form) */
 extern "C" void CAT(gecm_launch_stage1_f_, GECM_NL)(void *stream, const gecm_modconst *mc, const uint32_t *tape,
                                                      uint32_t tape_len, uint32_t *X, uint32_t *Z,
                                                      const uint32_t *S, size_t stride, int lanes, int form)
 {
-    if (form > 0) launch_stage1_special<ModF<GECM_NL>>(stream, mc, tape, tape_len, X, Z, S, stride, lanes);
+    if (form == 2) {
+        if constexpr (FPolicy<GECM_NL>::NF >= 3) launch_stage1_special<ModC<GECM_NL>>(stream, mc, tape, tape_len, X, Z, S, stride, lanes);
+    } else if (form > 0) launch_stage1_special<ModF<GECM_NL>>(stream, mc, tape, tape_len, X, Z, S, stride, lanes);
     else launch_stage1_special<ModP<GECM_NL>>(stream, mc, tape, tape_len, X, Z, S, stride, lanes);
 }
 

@@ -72,6 +72,7 @@ struct gecm_ctx {
      * (csrc/gecm_field.hpp); results are brought back modulo N by ff_settle() */
     gecm_dev *dev_f;
     int ff_k, ff_sign, ff_nl, ff_on, ff_pending, ff_loaded, last_on_f;
+    uint64_t ff_c;           /* Mw = 2^ff_k - ff_c for ff_sign > 0 (1: Mersenne form), 2^ff_k + 1 for ff_sign < 0 */
     uint64_t ff_tape_B1;
     mpl_t ff_M, ff_r_mod_m;  /* Mw; 2^(28 ff_nl) mod Mw */
     uint32_t *ff_n28;        /* n, kp, one for dev_f */
@@ -111,34 +112,45 @@ static void pow2_mod(mpl_t *r, unsigned e, const mpl_t *m)
     mpl_mod(r, &t, m);
 }
 
-/* N | 2^k - 1 or N | 2^k + 1 (the reference's isMersenne == +1 / -1, main.c:410-430): open a second device
- * context modulo Mw = 2^k -/+ 1 for the special stage-1 multiply (csrc/gecm_field.hpp, F-form / P-form)
- * when that is the cheaper multiply.  Failure to set it up is not an error: stage 1 then runs modulo N
+/* N | 2^k - 1, N | 2^k + 1 or N | 2^k - c with c below one reference limb (the reference's isMersenne == +1 / -1 / c,
+ * main.c:410-441): open a second device context modulo Mw = 2^k -/+ 1 or 2^k - c for the special stage-1 multiply
+ * (csrc/gecm_field.hpp, F-form / P-form / C-form) when that is the cheaper multiply.  Failure to set it up is not an error: stage 1 then runs modulo N
  * like everything else. */
 static void ff_setup(gecm_ctx *c)
 {
     cunningham_form f;
     cunningham_detect(&f, &c->N, c->digitbits);
-    if ((f.form != 1 && f.form != -1) || f.k < 64) return;
-    const int mbits = f.form > 0 ? f.k : f.k + 1;
+    if ((f.form != 1 && f.form != -1 && f.form != 2) || f.k < 64) return;
+    if (f.form == 2 && (f.c < 3 || !(f.c & 1))) return;              /* 2^k - c with c odd, c > 1 (c = 1 is form +1) */
+    const int mbits = f.form < 0 ? f.k + 1 : f.k;
     const int nlf = pick_nl(mbits);
     if (!nlf) return;
     const int G = gecm_dev_fform_generic_limbs(nlf);
     if (G < 0 || f.k < LIMB_BITS * (nlf - G)) return;                 /* limbs below nl-G must be F..F / 1,0..0 */
-    /* multiply-adds per modular multiplication: about nl^2 + G*nl against 2 nl^2 + nl */
-    if ((double)(nlf * nlf + G * nlf) * 1.15 > (double)(2 * c->nl * c->nl + c->nl)) return;
-    mpl_t one;
+    if (f.form == 2 && nlf - G < 3) return;                          /* limbs 0, 1 carry c - 1: one pure F limb above */
+    /* multiply-adds per modular multiplication: about nl^2 + G*nl (+ 3 nl for 2^k - c) against 2 nl^2 + nl */
+    if ((double)(nlf * nlf + (G + (f.form == 2 ? 3 : 0)) * nlf) * 1.15 > (double)(2 * c->nl * c->nl + c->nl)) return;
+    mpl_t one, t;
     mpl_set_u64(&one, 1);
     mpl_shl(&c->ff_M, &one, (unsigned)f.k);
-    if (f.form > 0) mpl_sub(&c->ff_M, &c->ff_M, &one);
+    if (f.form == 2) { mpl_set_u64(&t, f.c); mpl_sub(&c->ff_M, &c->ff_M, &t); }
+    else if (f.form > 0) mpl_sub(&c->ff_M, &c->ff_M, &one);
     else mpl_add(&c->ff_M, &c->ff_M, &one);
+    { mpl_t r; mpl_mod(&r, &c->ff_M, &c->N); if (!mpl_is_zero(&r)) return; }   /* N | Mw, or nothing below holds */
     pow2_mod(&c->ff_r_mod_m, (unsigned)(LIMB_BITS * nlf), &c->ff_M);
     c->ff_n28 = (uint32_t *)calloc((size_t)nlf * 3, sizeof(uint32_t));
     if (!c->ff_n28) return;
     mpl_to_limbs32(c->ff_n28, 1, nlf, LIMB_BITS, &c->ff_M);
     mpl_to_limbs32(c->ff_n28 + 2 * nlf, 1, nlf, LIMB_BITS, &c->ff_r_mod_m);
-    /* rho = -Mw^-1 mod 2^28: 1 for 2^k - 1, 2^28 - 1 for 2^k + 1 */
-    const uint32_t rho = f.form > 0 ? 1u : (1u << LIMB_BITS) - 1u;
+    /* rho = -Mw^-1 mod 2^28: 1 for 2^k - 1, 2^28 - 1 for 2^k + 1, (c mod 2^28)^-1 for 2^k - c */
+    uint32_t rho = f.form == 1 ? 1u : (1u << LIMB_BITS) - 1u;
+    if (f.form == 2) {
+        mpl_t two28, inv;
+        mpl_set_u64(&two28, 1u << LIMB_BITS);
+        if (!mpl_invmod(&inv, &c->ff_M, &two28)) { free(c->ff_n28); c->ff_n28 = NULL; return; }
+        mpl_sub(&inv, &two28, &inv);
+        rho = (uint32_t)mpl_get_u64(&inv);
+    }
     if (make_kp(c->ff_n28 + nlf, &c->ff_M, nlf) ||
         gecm_dev_open(&c->dev_f, c->device, nlf, c->ff_n28, c->ff_n28 + nlf, c->ff_n28 + 2 * nlf, rho)) {
         free(c->ff_n28);
@@ -148,7 +160,8 @@ static void ff_setup(gecm_ctx *c)
     }
     gecm_dev_set_fform(c->dev_f, f.form);
     c->ff_k = f.k;
-    c->ff_sign = f.form;
+    c->ff_sign = f.form < 0 ? -1 : 1;
+    c->ff_c = f.form == 2 ? f.c : 1;
     c->ff_nl = nlf;
     c->ff_on = 1;
 }

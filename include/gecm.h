@@ -129,15 +129,17 @@ int gecm_sync(gecm_ctx *ctx);
  * (gecm_dev_auto_lanes).  Results are identical in every layout.
  * gecm_get_lanes_per_curve returns what the last gecm_stage1 launch used (0 before the first). */
 int gecm_set_lanes_per_curve(gecm_ctx *ctx, int lanes);
-/* N | 2^k - 1 or N | 2^k + 1 (Cunningham cofactors; the reference's isMersenne == +1 / -1, main.c:410-430, for
- * which it switches to vecmulmod52_mersenne): stage 1 runs modulo 2^k -/+ 1 with a multiply whose reduction
+/* N | 2^k - 1, N | 2^k + 1 (Cunningham cofactors) or N | 2^k - c with c odd and below one reference limb (pseudo-
+ * Mersenne inputs); the reference's isMersenne == +1 / -1 / c, main.c:410-441, for which it switches to
+ * vecmulmod52_mersenne: stage 1 runs modulo 2^k -/+ 1 or 2^k - c with a multiply whose reduction
  * half needs almost no multiplications, and X, Z are reduced modulo N when they come back.  Chosen at
  * gecm_create when it is the cheaper multiply; outputs are the same residues modulo N either way.
  * gecm_set_special_form(ctx, 0) keeps everything on the generic REDC path (takes effect at the next
  * gecm_build_curves / gecm_upload_points).  A batch small enough for the eight-lane layout runs there, on
  * generic REDC, which is faster still.  gecm_get_special_form returns 0 if the special multiply is off or not
  * available, 1 if it is enabled, 2 if the last gecm_stage1 launch actually used it, and stores +k for
- * 2^k - 1, -k for 2^k + 1, and the limb count of that modulus (0, 0 if N has no such form or it would not pay). */
+ * 2^k - 1 and 2^k - c (c: gecm_prepare_input's info.c), -k for 2^k + 1, and the limb count of that modulus (0, 0 if N
+ * has no such form or it would not pay). */
 int gecm_set_special_form(gecm_ctx *ctx, int on);
 int gecm_get_special_form(const gecm_ctx *ctx, int *k, int *limbs);
 int gecm_get_lanes_per_curve(const gecm_ctx *ctx);

@@ -1,5 +1,5 @@
-"""Seeded differential fuzz on the GPU: random moduli (random odd N of 64..1030 bits, and Cunningham forms
-2^k -/+ 1 with random small cofactors removed), random B1 and sigma; every kernel flavour of stage 1 — one
+"""Seeded differential fuzz on the GPU: random moduli (random odd N of 64..1030 bits, Cunningham forms
+2^k -/+ 1 and pseudo-Mersenne forms 2^k - c with random small cofactors removed), random B1 and sigma; every kernel flavour of stage 1 — one
 two, eight and 32 lanes per curve, generic and special-form multiply — must write the save lines of the oracle
 (oracle/ecm_oracle.c, itself pinned to the reference's outputs)."""
 import ctypes
@@ -27,9 +27,18 @@ def orc():
 def _cases():
     rng = random.Random(20261004)
     out = []
-    for i in range(36):
-        kind = i % 3
-        if kind == 0:
+    for i in range(48):
+        kind = i % 4
+        if kind == 3:
+            # pseudo-Mersenne (main.c:432-441): N | 2^k - c with c odd below one reference limb
+            k = rng.randrange(300, 1025)
+            cc = rng.getrandbits(rng.choice((5, 20, 27, 28, 40, 50))) | 1
+            n = (1 << k) - cc
+            for p in (3, 5, 7, 11, 13, 17, 19, 23):
+                while n % p == 0 and rng.random() < 0.7:
+                    n //= p
+            name = "2^%d-%d" % (k, cc)
+        elif kind == 0:
             bits = rng.randrange(64, 1031)
             n = rng.getrandbits(bits) | (1 << (bits - 1)) | 1
             name = "rand%d" % bits

@@ -1,5 +1,5 @@
 """F-form (2^k - 1) stage 1 against the generic REDC path: same save lines, and kernel time of both.
-usage: python tools/fform_check.py k [curves] [B1] [lanes]     (negative k: N = 2^|k| + 1)"""
+usage: python tools/fform_check.py k [curves] [B1] [lanes] [c]     (negative k: N = 2^|k| + 1; c: N = 2^k - c)"""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "avx-ecm_amd"))
 import pyecm
@@ -7,9 +7,10 @@ k = int(sys.argv[1]) if len(sys.argv) > 1 else 401
 curves = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 b1 = int(sys.argv[3]) if len(sys.argv) > 3 else 5000
 lanes = int(sys.argv[4]) if len(sys.argv) > 4 else 0
-n = (1 << k) - 1 if k > 0 else (1 << -k) + 1
+cc = int(sys.argv[5]) if len(sys.argv) > 5 else 1
+n = (1 << k) - cc if k > 0 else (1 << -k) + 1
 eng = pyecm.Engine(n, digitbits=52)
-print("N = 2^%d %s 1, REDC limbs %d, special form:" % (abs(k), "-" if k > 0 else "+", eng.cfg.dev_limbs), eng.special_form(), flush=True)
+print("N = 2^%d %s %d, REDC limbs %d, special form:" % (abs(k), "-" if k > 0 else "+", cc, eng.cfg.dev_limbs), eng.special_form(), flush=True)
 sig = list(range(1000, 1000 + curves))
 res = {}
 for on in (True, False):
