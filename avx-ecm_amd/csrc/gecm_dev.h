@@ -66,8 +66,16 @@ int gecm_dev_l0(gecm_dev *d, int op, const uint32_t *a, const uint32_t *b, uint3
 int gecm_dev_set_s2const(gecm_dev *d, const uint32_t *r3, uint32_t inv_iters);
 /* ecm_stage2_init: baby-step table (npb entries, X/Z normalised), Pd = [D]Q, acc = one.
  * keep: bitmap over j in [0, umax], bit set iff j is stored.  L = ring half-size (2L giant steps). */
+/* K = gecm_dev_s2_subseq(d) sub-sequences per curve (1: the plain chain).  For K > 1: tgt_off[r] .. tgt_off[r+1] is
+ * the range of tgt[] holding the table indices of the kept members j = r, r+K, ... (r = 0: K, 2K, ...) of
+ * sub-sequence r, in order; tgt_off has K + 1 entries. */
+uint32_t gecm_dev_s2_subseq(gecm_dev *d);
 int gecm_dev_s2_init(gecm_dev *d, const uint32_t *keep, size_t keep_words, uint32_t umax, uint32_t D,
-                     uint32_t npb, uint32_t G, uint32_t ring_size);
+                     uint32_t npb, uint32_t G, uint32_t ring_size, const uint32_t *tgt, const uint32_t *tgt_off,
+                     uint32_t K);
+/* failure records come in planes of [limb][curve]: plane 0 from the single-chain inversions, plane 1 + r from
+ * sub-sequence r; gecm_dev_s2_download fills all of them */
+uint32_t gecm_dev_s2_fail_planes(gecm_dev *d);
 /* ecm_stage2_pair for one range: steps = nsteps words pairs: (0xffffffff, n) = generate the next n
  * giant steps (n <= G), else (ring slot, table index).  G = chunk size, ring_size = power of two. */
 int gecm_dev_s2_pair(gecm_dev *d, const uint32_t *steps, uint32_t nsteps, uint32_t D, uint32_t G,

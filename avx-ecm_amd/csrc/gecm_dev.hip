@@ -48,6 +48,9 @@ struct gecm_dev {
     size_t flags_cap = 0;
     size_t s2_npb = 0, s2_G = 0, s2_ring = 0, s2_stride = 0, steps_cap = 0, keep_cap = 0;
     uint32_t s2_slices = 1;   // stage-2 accumulators per curve (pair-walk slices), see gecm_dev_s2_init
+    uint32_t s2_K = 1;        // sub-sequences per curve for the table build and the giant steps (gecm_dev_s2_subseq)
+    uint32_t *dKBlk = nullptr, *dKPa = nullptr, *dPdK = nullptr, *dTgt = nullptr;
+    size_t tgt_cap = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_ms = 0.f;
@@ -144,6 +147,8 @@ static void free_s2(gecm_dev *d)
 {
     (void)hipFree(d->dPbX); (void)hipFree(d->dBlk); (void)hipFree(d->dPd); (void)hipFree(d->dAcc);
     (void)hipFree(d->dFail); (void)hipFree(d->dPa);
+    (void)hipFree(d->dKBlk); (void)hipFree(d->dKPa); (void)hipFree(d->dPdK);
+    d->dKBlk = d->dKPa = d->dPdK = nullptr;
     d->dPbX = d->dBlk = d->dPd = d->dAcc = d->dFail = d->dPa = nullptr;
     d->s2_npb = d->s2_G = d->s2_ring = d->s2_stride = 0;
 }
@@ -446,8 +451,29 @@ extern "C" size_t gecm_dev_s2_bytes(int nl, size_t ncurves, uint32_t npb, uint32
     return coord * ((size_t)npb + 3 * GECM_S2_BLK + 2 + 1 + 32 /* acc slices, upper bound */ + 2 * ((size_t)G + 2) + (size_t)G + (size_t)ring_size);
 }
 
+/* Sub-sequences per curve for the stage-2 table build and giant steps: those are one dependent chain per curve, so a
+ * batch of a few thousand curves (a few dozen wavefronts) is split into K interleaved chains per curve until there
+ * are 2 wavefronts per SIMD (csrc/gecm_stage2.hpp, s2_init_k / giant_chunk_k).  1 for batches that fill the chip.
+ * GECM_S2_SUBSEQ=1..32 (a power of two) overrides, for measurements. */
+extern "C" uint32_t gecm_dev_s2_subseq(gecm_dev *d)
+{
+    // one wavefront per SIMD is the target: every sub-sequence pays one inversion per chunk (about as much as a
+    // thousand multiplications), and at 4096 curves K = 16 measured 0.73 s for B2 = 1e8 against 0.79 s with K = 32
+    const size_t waves = d->stride / 64, want = (size_t)d->cus * 4;
+    uint32_t k = 1;
+    while (k < 32 && waves * (k * 2) <= want) k *= 2;
+    if (const char *e = getenv("GECM_S2_SUBSEQ")) {
+        const long v = strtol(e, nullptr, 10);
+        if (v >= 1 && v <= 32 && (v & (v - 1)) == 0) k = (uint32_t)v;
+    }
+    return k;
+}
+
+extern "C" uint32_t gecm_dev_s2_fail_planes(gecm_dev *d) { return d->s2_K > 1 ? d->s2_K + 1 : 1; }
+
 extern "C" int gecm_dev_s2_init(gecm_dev *d, const uint32_t *keep, size_t keep_words, uint32_t umax, uint32_t D,
-                                uint32_t npb, uint32_t G, uint32_t ring_size)
+                                uint32_t npb, uint32_t G, uint32_t ring_size, const uint32_t *tgt, const uint32_t *tgt_off,
+                                uint32_t K)
 {
     HIPCHK(hipSetDevice(d->device));
     if (!d->stride || d->r3.empty()) {
@@ -455,8 +481,13 @@ extern "C" int gecm_dev_s2_init(gecm_dev *d, const uint32_t *keep, size_t keep_w
         return -2;
     }
     const size_t coord = (size_t)d->nl * d->stride * sizeof(uint32_t);
-    if (d->s2_npb != npb || d->s2_G != G || d->s2_ring != ring_size || d->s2_stride != d->stride) {
+    if (K < 1 || K > 32 || (K & (K - 1)) || (K > 1 && (!tgt || !tgt_off))) {
+        g_err = "gecm_dev_s2_init: bad number of sub-sequences";
+        return -2;
+    }
+    if (d->s2_npb != npb || d->s2_G != G || d->s2_ring != ring_size || d->s2_stride != d->stride || d->s2_K != K) {
         free_s2(d);
+        d->s2_K = K;
         HIPCHK(hipMalloc(&d->dPbX, coord * npb));
         HIPCHK(hipMalloc(&d->dBlk, coord * 3 * GECM_S2_BLK));    // bx, bz, bp: S2_BLK entries each
         HIPCHK(hipMalloc(&d->dPd, coord * 2));
@@ -473,7 +504,13 @@ extern "C" int gecm_dev_s2_init(gecm_dev *d, const uint32_t *keep, size_t keep_w
             }
         }
         HIPCHK(hipMalloc(&d->dAcc, coord * d->s2_slices));
-        HIPCHK(hipMalloc(&d->dFail, coord));
+        HIPCHK(hipMalloc(&d->dFail, coord * (K > 1 ? K + 1 : 1)));       // plane 0 + one per sub-sequence
+        if (K > 1) {
+            const size_t Gs = G / K + 1;
+            HIPCHK(hipMalloc(&d->dKBlk, coord * K * 3 * GECM_S2_BLK));    // kbx, kbz, kbp per (curve block, r)
+            HIPCHK(hipMalloc(&d->dKPa, coord * K * (2 * (Gs + 2) + Gs)));  // kgx, kgz (Gs+2 entries), kgp (Gs)
+            HIPCHK(hipMalloc(&d->dPdK, coord * 2));
+        }
         // giant steps: gx, gz (G+2 entries each), gp (G), ring (ring_size)
         HIPCHK(hipMalloc(&d->dPa, coord * (2 * ((size_t)G + 2) + (size_t)G + (size_t)ring_size)));
         d->s2_npb = npb; d->s2_G = G; d->s2_ring = ring_size; d->s2_stride = d->stride;
@@ -485,7 +522,18 @@ extern "C" int gecm_dev_s2_init(gecm_dev *d, const uint32_t *keep, size_t keep_w
         d->keep_cap = keep_words;
     }
     HIPCHK(hipMemcpyAsync(d->dKeep, keep, keep_words * 4, hipMemcpyHostToDevice, d->stream));
-    HIPCHK(hipMemsetAsync(d->dFail, 0, coord, d->stream));
+    if (K > 1) {
+        const size_t tw = (size_t)tgt_off[K] + (K + 1);                 // target lists, then the K + 1 offsets
+        if (tw > d->tgt_cap) {
+            (void)hipFree(d->dTgt);
+            d->dTgt = nullptr;
+            HIPCHK(hipMalloc(&d->dTgt, tw * 4));
+            d->tgt_cap = tw;
+        }
+        HIPCHK(hipMemcpyAsync(d->dTgt, tgt, (size_t)tgt_off[K] * 4, hipMemcpyHostToDevice, d->stream));
+        HIPCHK(hipMemcpyAsync(d->dTgt + tgt_off[K], tgt_off, (K + 1) * 4, hipMemcpyHostToDevice, d->stream));
+    }
+    HIPCHK(hipMemsetAsync(d->dFail, 0, coord * (K > 1 ? K + 1 : 1), d->stream));
     HIPCHK(hipMemsetAsync(d->dPbX, 0, coord, d->stream));        // entry 0 (unused) defined
     gecm_s2_init_args a;
     a.X = d->dX; a.Z = d->dZ; a.S = d->dS;
@@ -494,6 +542,15 @@ extern "C" int gecm_dev_s2_init(gecm_dev *d, const uint32_t *keep, size_t keep_w
     a.PdX = d->dPd; a.PdZ = d->dPd + coord / 4;
     a.acc = d->dAcc; a.fail = d->dFail; a.keep = d->dKeep;
     a.umax = umax; a.D = D; a.npb = npb; a.stride = d->stride;
+    a.K = K;
+    a.tgt = a.tgt_off = nullptr;
+    a.kbx = a.kbz = a.kbp = a.PdKX = a.PdKZ = nullptr;
+    if (K > 1) {
+        const size_t kw = (coord / 4) * K * GECM_S2_BLK;
+        a.tgt = d->dTgt; a.tgt_off = d->dTgt + tgt_off[K];
+        a.kbx = d->dKBlk; a.kbz = d->dKBlk + kw; a.kbp = d->dKBlk + 2 * kw;
+        a.PdKX = d->dPdK; a.PdKZ = d->dPdK + coord / 4;
+    }
     gecm_modconst mc = modconst(d);
     HIPCHK(hipEventRecord(d->ev0, d->stream));
     switch (d->nl) {
@@ -536,6 +593,13 @@ extern "C" int gecm_dev_s2_pair(gecm_dev *d, const uint32_t *steps, uint32_t nst
     a.acc = d->dAcc; a.fail = d->dFail; a.steps = d->dSteps; a.host_steps = steps;
     a.nsteps = nsteps; a.D = D; a.G = G; a.ring_size = ring_size; a.A0 = A0; a.stride = d->stride;
     a.slices = d->s2_slices;
+    a.K = d->s2_K; a.Gs = (uint32_t)(G / d->s2_K + 1);
+    a.kgx = a.kgz = a.kgp = nullptr; a.PdKX = a.PdKZ = nullptr;
+    if (d->s2_K > 1) {
+        const size_t kcw = cw * d->s2_K;
+        a.kgx = d->dKPa; a.kgz = a.kgx + kcw * ((size_t)a.Gs + 2); a.kgp = a.kgz + kcw * ((size_t)a.Gs + 2);
+        a.PdKX = d->dPdK; a.PdKZ = d->dPdK + cw;
+    }
     gecm_modconst mc = modconst(d);
     HIPCHK(hipEventRecord(d->ev0, d->stream));
     switch (d->nl) {
@@ -560,7 +624,11 @@ extern "C" int gecm_dev_s2_download(gecm_dev *d, uint32_t *acc, uint32_t *fail)
         return -2;
     }
     if (download_soa(d, acc, d->dAcc)) return -1;
-    if (fail && download_soa(d, fail, d->dFail)) return -1;
+    if (fail) {          /* gecm_dev_s2_fail_planes() planes of [limb][ncurves] */
+        const uint32_t planes = gecm_dev_s2_fail_planes(d);
+        for (uint32_t p = 0; p < planes; p++)
+            if (download_soa(d, fail + (size_t)p * d->nl * d->ncurves, d->dFail + (size_t)p * d->nl * d->stride)) return -1;
+    }
     HIPCHK(hipStreamSynchronize(d->stream));
     return 0;
 }

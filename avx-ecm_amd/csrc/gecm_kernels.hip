@@ -238,11 +238,24 @@ __global__ void __launch_bounds__(64, 2) k_s2_init(S2InitArgs a, S2Const<NL> k)
     s2_init<NL>(a, k, blockIdx.x * 64u + threadIdx.x);
 }
 
+// K sub-sequences per curve (small batches): block b works on curve block b / K, sub-sequence b % K
+template <int NL>
+__global__ void __launch_bounds__(64, 2) k_s2_init_k(S2InitArgs a, S2Const<NL> k)
+{
+    s2_init_k<NL>(a, k, (blockIdx.x / a.K) * 64u + threadIdx.x, blockIdx.x % a.K);
+}
+
+template <int NL>
+__global__ void __launch_bounds__(64, 2) k_s2_gen_k(S2PairArgs a, uint32_t first_abs, uint32_t n, S2Const<NL> k)
+{
+    giant_chunk_k<NL>(a, first_abs, n, k, (blockIdx.x / a.K) * 64u + threadIdx.x, blockIdx.x % a.K);
+}
+
 // giant steps [first_abs, first_abs+n): generate + normalise into the ring
 template <int NL>
-__global__ void __launch_bounds__(64, 2) k_s2_gen(S2PairArgs a, uint32_t first_abs, uint32_t n, S2Const<NL> k)
+__global__ void __launch_bounds__(64, 2) k_s2_gen(S2PairArgs a, uint32_t first_abs, uint32_t n, uint32_t kprev, S2Const<NL> k)
 {
-    giant_chunk<NL>(a, first_abs, n, first_abs == 0, k, blockIdx.x * 64u + threadIdx.x);
+    giant_chunk<NL>(a, first_abs, n, first_abs == 0, k, blockIdx.x * 64u + threadIdx.x, kprev);
 }
 
 // pair walk over tape entries [first, first+count)
@@ -396,8 +409,14 @@ extern "C" void CAT(gecm_launch_s2_init_, GECM_NL)(void *stream, const gecm_modc
     a.X = h->X; a.Z = h->Z; a.S = h->S; a.PbX = h->PbX; a.bx = h->bx; a.bz = h->bz; a.bp = h->bp;
     a.PdX = h->PdX; a.PdZ = h->PdZ; a.acc = h->acc; a.fail = h->fail; a.keep = h->keep;
     a.umax = h->umax; a.D = h->D; a.npb = h->npb; a.stride = h->stride;
-    hipLaunchKernelGGL(k_s2_init<GECM_NL>, dim3((unsigned)(h->stride / 64)), dim3(64), 0, (hipStream_t)stream, a,
-                       make_s2<GECM_NL>(mc));
+    a.K = h->K; a.tgt = h->tgt; a.tgt_off = h->tgt_off; a.kbx = h->kbx; a.kbz = h->kbz; a.kbp = h->kbp;
+    a.PdKX = h->PdKX; a.PdKZ = h->PdKZ;
+    if (h->K > 1)
+        hipLaunchKernelGGL(k_s2_init_k<GECM_NL>, dim3((unsigned)(h->stride / 64 * h->K)), dim3(64), 0, (hipStream_t)stream, a,
+                           make_s2<GECM_NL>(mc));
+    else
+        hipLaunchKernelGGL(k_s2_init<GECM_NL>, dim3((unsigned)(h->stride / 64)), dim3(64), 0, (hipStream_t)stream, a,
+                           make_s2<GECM_NL>(mc));
 }
 
 extern "C" void CAT(gecm_launch_s2_pair_, GECM_NL)(void *stream, const gecm_modconst *mc, const gecm_s2_pair_args *h)
@@ -407,16 +426,27 @@ extern "C" void CAT(gecm_launch_s2_pair_, GECM_NL)(void *stream, const gecm_modc
     a.gx = h->gx; a.gz = h->gz; a.gp = h->gp; a.ring = h->ring; a.acc = h->acc; a.fail = h->fail;
     a.steps = h->steps; a.nsteps = h->nsteps; a.D = h->D; a.G = h->G; a.ring_size = h->ring_size; a.A0 = h->A0;
     a.stride = h->stride;
+    a.K = h->K; a.Gs = h->Gs; a.kgx = h->kgx; a.kgz = h->kgz; a.kgp = h->kgp; a.PdKX = h->PdKX; a.PdKZ = h->PdKZ;
     // the tape on the host decides the launch sequence: one k_s2_gen per "generate" mark, one
     // k_s2_pairs per run of pairs between marks (~84 + 84 launches per 1e8 range)
     const dim3 grid((unsigned)(h->stride / 64)), block(64);
     const dim3 pgrid((unsigned)(h->stride / 64), h->slices ? h->slices : 1);
     const S2Const<GECM_NL> k = make_s2<GECM_NL>(mc);
-    uint32_t generated = 0, i = 0;
+    // a "generate" mark with bit 31 set in its count is a single-chain chunk (the reference's last batch of the range,
+    // gecm_stage2_pair); the others use K sub-sequences per curve when the batch is small (h->K > 1)
+    const dim3 kgrid((unsigned)(h->stride / 64 * (h->K ? h->K : 1)));
+    uint32_t generated = 0, i = 0, kprev = 1;
     while (i < h->nsteps) {
         if (h->host_steps[2 * i] == S2_STEP_GEN) {
-            uint32_t n = h->host_steps[2 * i + 1];
-            hipLaunchKernelGGL(k_s2_gen<GECM_NL>, grid, block, 0, (hipStream_t)stream, a, generated, n, k);
+            const uint32_t word = h->host_steps[2 * i + 1];
+            const uint32_t n = word & 0x7fffffffu;
+            if (h->K > 1 && !(word & 0x80000000u)) {
+                hipLaunchKernelGGL(k_s2_gen_k<GECM_NL>, kgrid, block, 0, (hipStream_t)stream, a, generated, n, k);
+                kprev = h->K;
+            } else {
+                hipLaunchKernelGGL(k_s2_gen<GECM_NL>, grid, block, 0, (hipStream_t)stream, a, generated, n, generated ? kprev : 1u, k);
+                kprev = 1;
+            }
             generated += n;
             i++;
         } else {

@@ -25,6 +25,10 @@ typedef struct {
     const uint32_t *keep;
     uint32_t umax, D, npb;
     size_t stride;
+    /* K > 1: K sub-sequences per curve (csrc/gecm_stage2.hpp, s2_init_k) */
+    uint32_t K;
+    const uint32_t *tgt, *tgt_off;
+    uint32_t *kbx, *kbz, *kbp, *PdKX, *PdKZ;
 } gecm_s2_init_args;
 
 typedef struct {
@@ -37,6 +41,10 @@ typedef struct {
     uint32_t slices;              /* accumulators per curve: each run of pairs is cut into this many slices */
     uint64_t A0;
     size_t stride;
+    /* K > 1: giant steps with K sub-sequences per curve (giant_chunk_k); Gs = entries per sub-sequence and chunk */
+    uint32_t K, Gs;
+    uint32_t *kgx, *kgz, *kgp;
+    const uint32_t *PdKX, *PdKZ;
 } gecm_s2_pair_args;
 
 #define GECM_DECL(nl)                                                                                     \

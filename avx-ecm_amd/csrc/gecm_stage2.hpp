@@ -185,34 +185,42 @@ __device__ __forceinline__ void fe_inv_mont(Fe<NL> &r, const Fe<NL> &a, const S2
 
 // Montgomery's trick on n <= S2_BLK points whose X, Z sit in bx, bz (block tables):
 // out[e0 + i] = X_i / Z_i (Montgomery form, lazy-normalised).  bp = scratch for prefix products.
+// tgt == nullptr: entry i of the block goes to table entry e0 + i; else to tgt[e0 + i] (a sub-sequence's kept
+// entries are not consecutive in the table).  sidx = index used for the block scratch (a virtual curve per
+// sub-sequence), idx = the curve's own index (table, failure record).
 template <int NL>
 __device__ __forceinline__ void block_normalise(uint32_t *__restrict__ out, uint32_t out_nent, size_t e0,
                                                 const uint32_t *__restrict__ bx, const uint32_t *__restrict__ bz,
                                                 uint32_t *__restrict__ bp, uint32_t n, const S2Const<NL> &k,
-                                                uint32_t *__restrict__ fail, size_t stride, uint32_t idx)
+                                                uint32_t *__restrict__ fail, size_t stride, uint32_t idx,
+                                                const uint32_t *__restrict__ tgt = nullptr, uint32_t sidx = 0xffffffffu)
 {
+    if (sidx == 0xffffffffu) sidx = idx;
+    auto where = [&](size_t i) -> size_t {
+        return tgt ? (size_t)__builtin_amdgcn_readfirstlane(tgt[e0 + i]) : e0 + i;
+    };
     Fe<NL> acc, z, x, t;
-    tb_load(acc, bz, S2_BLK, idx, 0);
-    tb_store(bp, S2_BLK, idx, 0, acc);
+    tb_load(acc, bz, S2_BLK, sidx, 0);
+    tb_store(bp, S2_BLK, sidx, 0, acc);
     for (uint32_t i = 1; i < n; i++) {            // prefix products  (ecm.c:1889-1893)
-        tb_load(z, bz, S2_BLK, idx, i);
+        tb_load(z, bz, S2_BLK, sidx, i);
         fe_mul(acc, acc, z, k.m);
-        tb_store(bp, S2_BLK, idx, i, acc);
+        tb_store(bp, S2_BLK, sidx, i, acc);
     }
     Fe<NL> inv;
     fe_inv_mont(inv, acc, k, fail, stride, idx);  // (prod Z)^-1
     for (uint32_t i = n - 1; i > 0; i--) {        // suffix walk  (ecm.c:1965-1987)
-        tb_load(t, bp, S2_BLK, idx, i - 1);
+        tb_load(t, bp, S2_BLK, sidx, i - 1);
         fe_mul(t, t, inv, k.m);                   // Z_i^-1
-        tb_load(z, bz, S2_BLK, idx, i);
+        tb_load(z, bz, S2_BLK, sidx, i);
         fe_mul(inv, inv, z, k.m);
-        tb_load(x, bx, S2_BLK, idx, i);
+        tb_load(x, bx, S2_BLK, sidx, i);
         fe_mul(x, x, t, k.m);
-        tb_store(out, out_nent, idx, e0 + i, x);
+        tb_store(out, out_nent, idx, where(i), x);
     }
-    tb_load(x, bx, S2_BLK, idx, 0);
+    tb_load(x, bx, S2_BLK, sidx, 0);
     fe_mul(x, x, inv, k.m);
-    tb_store(out, out_nent, idx, e0, x);
+    tb_store(out, out_nent, idx, where(0), x);
 }
 
 // P <- [c]P, binary ladder (next_pt_vec, ecm.c:886-976); c is wave-uniform.
@@ -257,6 +265,12 @@ struct S2InitArgs {
     const uint32_t *keep;            // bitmap over j: bit j set iff map[j] > 0
     uint32_t umax, D, npb;
     size_t stride;
+    // K sub-sequences per curve (small batches, s2_init_k): table index of the i-th kept member of sub-sequence r
+    // at tgt[tgt_off[r] + i]; block scratch kbx/kbz/kbp per (curve block, r); PdK = [K*D]Q for the giant steps
+    uint32_t K;
+    const uint32_t *tgt, *tgt_off;
+    uint32_t *kbx, *kbz, *kbp;
+    uint32_t *PdKX, *PdKZ;
 };
 
 // ecm_stage2_init, ecm.c:2201-2340
@@ -308,6 +322,71 @@ __device__ __forceinline__ void s2_init(const S2InitArgs &a, const S2Const<NL> &
     fe_store(a.acc, stride, idx, k.one);        // acc = one   ecm.c:2318
 }
 
+// ecm_stage2_init with K sub-sequences per curve: sub-sequence r holds the multiples j = r, r+K, r+2K, ... (j >= 1;
+// r = 0 starts at K) and steps by [K]Q: P_(j+K) = P_j + [K]Q with difference P_(j-K) — the same points [j]Q as the
+// reference's chain j -> j+1 (ecm.c:2263-2313), as other projective representatives, and only X/Z of them is kept.
+// A batch of a few thousand curves is a few dozen wavefronts; with K = 32 chains per curve it fills the chip.
+// r is wave-uniform (blockIdx.x % K); idx is the curve.
+template <int NL>
+__device__ __forceinline__ void s2_init_k(const S2InitArgs &a, const S2Const<NL> &k, uint32_t idx, uint32_t r)
+{
+    const ModK<NL> &m = k.m;
+    const size_t stride = a.stride;
+    const uint32_t K = a.K;
+    const uint32_t sidx = ((idx >> 6) * K + r) * 64u + (idx & 63u);      // virtual curve: scratch of (curve block, r)
+    Pt<NL> Q, PK, p1, p2;
+    Fe<NL> s4, sK, dK;
+    fe_load(Q.X, a.X, stride, idx);
+    fe_load(Q.Z, a.Z, stride, idx);
+    fe_load(s4, a.S, stride, idx);
+    PK = Q;
+    pt_ladder(PK, (uint64_t)K, s4, m);
+    pt_sumdiff(sK, dK, PK, m);
+    const uint32_t j0 = r ? r : K;                  // first member
+    const uint32_t toff = __builtin_amdgcn_readfirstlane(a.tgt_off[r]);
+    uint32_t nblk = 0, e0 = toff;
+    uint32_t mi = 0;
+    for (uint32_t j = j0; j <= a.umax; j += K, mi++) {
+        Pt<NL> T;
+        if (mi < 2) {
+            T = Q;
+            pt_ladder(T, (uint64_t)j, s4, m);       // the first two members by the ladder (next_pt_vec)
+        } else {
+            Fe<NL> s1, d1, pp, mm;
+            pt_sumdiff(s1, d1, p1, m);
+            pt_add_uv(pp, mm, s1, d1, sK, dK, m);
+            fe_mul(T.X, pp, p2.Z, m);
+            fe_mul(T.Z, mm, p2.X, m);
+        }
+        uint32_t kb = (a.keep[j >> 5] >> (j & 31)) & 1u;
+        kb = __builtin_amdgcn_readfirstlane(kb);
+        if (kb) {
+            tb_store(a.kbx, S2_BLK, sidx, nblk, T.X);
+            tb_store(a.kbz, S2_BLK, sidx, nblk, T.Z);
+            nblk++;
+            if (nblk == S2_BLK) {
+                block_normalise<NL>(a.PbX, a.npb, e0, a.kbx, a.kbz, a.kbp, nblk, k, a.fail, stride, idx, a.tgt, sidx);
+                e0 += nblk;
+                nblk = 0;
+            }
+        }
+        p2 = p1;
+        p1 = T;
+    }
+    if (nblk) block_normalise<NL>(a.PbX, a.npb, e0, a.kbx, a.kbz, a.kbp, nblk, k, a.fail, stride, idx, a.tgt, sidx);
+    if (r == 0) {
+        Pt<NL> Pd = Q;
+        pt_ladder(Pd, (uint64_t)a.D, s4, m);        // Pd = [w]Q   ecm.c:2332-2334
+        Fe<NL> c;
+        fe_canonical_mont(c, Pd.X, k.one, m); fe_store(a.PdX, stride, idx, c);
+        fe_canonical_mont(c, Pd.Z, k.one, m); fe_store(a.PdZ, stride, idx, c);
+        pt_ladder(Pd, (uint64_t)K, s4, m);          // [K*D]Q: the giant steps' stride (giant_chunk_k)
+        fe_canonical_mont(c, Pd.X, k.one, m); fe_store(a.PdKX, stride, idx, c);
+        fe_canonical_mont(c, Pd.Z, k.one, m); fe_store(a.PdKZ, stride, idx, c);
+        fe_store(a.acc, stride, idx, k.one);        // acc = one   ecm.c:2318
+    }
+}
+
 struct S2PairArgs {
     const uint32_t *X, *Z, *S;       // Q, s
     const uint32_t *PbX;             // normalised baby steps
@@ -323,6 +402,11 @@ struct S2PairArgs {
     uint32_t nsteps, D, G, ring_size;
     uint64_t A0;                     // multiplier of the first giant step: 2*amin*D   ecm.c:2378
     size_t stride;
+    // K sub-sequences per curve (giant_chunk_k): scratch per (curve block, r) with Gs + 2 / Gs entries, the stride
+    // point [K*D]Q, and one failure plane per sub-sequence after plane 0
+    uint32_t K, Gs;
+    uint32_t *kgx, *kgz, *kgp;
+    const uint32_t *PdKX, *PdKZ;
 };
 
 // tape word 0 == S2_STEP_GEN: generate the next `word 1` giant steps (continuing the sequence) and
@@ -333,9 +417,11 @@ struct S2PairArgs {
 // ones and inverts them (ecm.c:2458-2502): 1,341 inversions at B2 = 1e8.  Here they are produced in
 // chunks of G >> 2U steps with ONE inversion per chunk; the ring holds the normalised X/Z of every
 // step a pair can still ask for.  Same points, same (unique) inverses, same accumulator.
+// kprev > 1: the steps before first_abs were made by giant_chunk_k with kprev sub-sequences; the two previous steps are
+// then the latest members of sub-sequences (first_abs-1) % kprev and (first_abs-2) % kprev.
 template <int NL>
 __device__ __forceinline__ void giant_chunk(const S2PairArgs &a, uint32_t first_abs, uint32_t n, bool very_first,
-                                            const S2Const<NL> &k, uint32_t idx)
+                                            const S2Const<NL> &k, uint32_t idx, uint32_t kprev = 1)
 {
     // its own kernel launch (k_s2_gen, ~84 per curve batch at B2=1e8): everything it needs is read from
     // memory, so the pair-walk kernel keeps only the accumulator and two operand pairs live
@@ -370,6 +456,11 @@ __device__ __forceinline__ void giant_chunk(const S2PairArgs &a, uint32_t first_
         p2 = P0;
         p1 = T;
         start = 2;
+    } else if (kprev > 1) {
+        const uint32_t r1 = (first_abs - 1) % kprev, r2 = (first_abs - 2) % kprev;
+        const uint32_t v1 = ((idx >> 6) * kprev + r1) * 64u + (idx & 63u), v2 = ((idx >> 6) * kprev + r2) * 64u + (idx & 63u);
+        tb_load(p1.X, a.kgx, a.Gs + 2, v1, 1); tb_load(p1.Z, a.kgz, a.Gs + 2, v1, 1);
+        tb_load(p2.X, a.kgx, a.Gs + 2, v2, 1); tb_load(p2.Z, a.kgz, a.Gs + 2, v2, 1);
     } else {
         tb_load(p2.X, a.gx, a.G + 2, idx, 0); tb_load(p2.Z, a.gz, a.G + 2, idx, 0);
         tb_load(p1.X, a.gx, a.G + 2, idx, 1); tb_load(p1.Z, a.gz, a.G + 2, idx, 1);
@@ -413,6 +504,79 @@ __device__ __forceinline__ void giant_chunk(const S2PairArgs &a, uint32_t first_
     tb_load(x, a.gx, a.G + 2, idx, 2);
     fe_mul(x, x, inv, m);
     tb_store(a.ring, a.ring_size, idx, first_abs & rmask, x);
+}
+
+// Giant steps [first_abs, first_abs + n) with K sub-sequences per curve: sub-sequence r makes the steps s = r (mod K),
+// P_s = P_(s-K) + [K*D]Q with difference P_(s-2K) (its first two members by the ladder), normalises ITS members with
+// its own inversion and writes them to the ring.  Same points, same X/Z.  State between chunks: the latest two members
+// in scratch entries 0, 1 of (curve block, r).  A failing inversion is recorded in plane 1 + r of `fail` (plane 0
+// belongs to the single-chain chunks, whose last one reproduces the reference's last batch).
+template <int NL>
+__device__ __forceinline__ void giant_chunk_k(const S2PairArgs &a, uint32_t first_abs, uint32_t n, const S2Const<NL> &k,
+                                              uint32_t idx, uint32_t r)
+{
+    const ModK<NL> &m = k.m;
+    const size_t stride = a.stride;
+    const uint32_t K = a.K;
+    const uint32_t s0 = first_abs + (r + K - first_abs % K) % K;            // first step of this sub-sequence in the chunk
+    if (s0 >= first_abs + n) return;                                        // wave-uniform
+    const uint32_t cnt = (first_abs + n - 1 - s0) / K + 1;
+    const uint32_t m0 = s0 / K;                                             // member number of s0 (s = r + member*K)
+    const uint32_t v = ((idx >> 6) * K + r) * 64u + (idx & 63u);
+    Pt<NL> Q, PdK, p1, p2;
+    Fe<NL> s4, sD, dD;
+    fe_load(PdK.X, a.PdKX, stride, idx);
+    fe_load(PdK.Z, a.PdKZ, stride, idx);
+    pt_sumdiff(sD, dD, PdK, m);
+    if (m0 < 2) {
+        fe_load(Q.X, a.X, stride, idx);
+        fe_load(Q.Z, a.Z, stride, idx);
+        fe_load(s4, a.S, stride, idx);
+    }
+    if (m0 >= 1) { tb_load(p1.X, a.kgx, a.Gs + 2, v, 1); tb_load(p1.Z, a.kgz, a.Gs + 2, v, 1); }
+    if (m0 >= 2) { tb_load(p2.X, a.kgx, a.Gs + 2, v, 0); tb_load(p2.Z, a.kgz, a.Gs + 2, v, 0); }
+    for (uint32_t j = 0; j < cnt; j++) {
+        Pt<NL> T;
+        if (m0 + j < 2) {
+            T = Q;
+            pt_ladder(T, a.A0 + (uint64_t)(s0 + j * K) * a.D, s4, m);       // [A + s*D]Q   ecm.c:2380-2383
+        } else {
+            Fe<NL> s1, d1, pp, mm;
+            pt_sumdiff(s1, d1, p1, m);
+            pt_add_uv(pp, mm, s1, d1, sD, dD, m);
+            fe_mul(T.X, pp, p2.Z, m);
+            fe_mul(T.Z, mm, p2.X, m);
+        }
+        tb_store(a.kgx, a.Gs + 2, v, j + 2, T.X);
+        tb_store(a.kgz, a.Gs + 2, v, j + 2, T.Z);
+        p2 = p1;
+        p1 = T;
+    }
+    if (m0 + cnt >= 2) { tb_store(a.kgx, a.Gs + 2, v, 0, p2.X); tb_store(a.kgz, a.Gs + 2, v, 0, p2.Z); }
+    tb_store(a.kgx, a.Gs + 2, v, 1, p1.X); tb_store(a.kgz, a.Gs + 2, v, 1, p1.Z);
+    Fe<NL> acc, z, x, t;
+    tb_load(acc, a.kgz, a.Gs + 2, v, 2);
+    tb_store(a.kgp, a.Gs, v, 0, acc);
+    for (uint32_t i = 1; i < cnt; i++) {
+        tb_load(z, a.kgz, a.Gs + 2, v, i + 2);
+        fe_mul(acc, acc, z, m);
+        tb_store(a.kgp, a.Gs, v, i, acc);
+    }
+    Fe<NL> inv;
+    fe_inv_mont(inv, acc, k, a.fail + (size_t)(1 + r) * NL * stride, stride, idx);
+    const uint32_t rmask = a.ring_size - 1;
+    for (uint32_t i = cnt - 1; i > 0; i--) {
+        tb_load(t, a.kgp, a.Gs, v, i - 1);
+        fe_mul(t, t, inv, m);
+        tb_load(z, a.kgz, a.Gs + 2, v, i + 2);
+        fe_mul(inv, inv, z, m);
+        tb_load(x, a.kgx, a.Gs + 2, v, i + 2);
+        fe_mul(x, x, t, m);
+        tb_store(a.ring, a.ring_size, idx, (s0 + i * K) & rmask, x);
+    }
+    tb_load(x, a.kgx, a.Gs + 2, v, 2);
+    fe_mul(x, x, inv, m);
+    tb_store(a.ring, a.ring_size, idx, s0 & rmask, x);
 }
 
 // The pair walk of ecm_stage2_pair (ecm.c:2448-2533) over tape entries [first, first+count): every

@@ -61,6 +61,11 @@ struct gecm_ctx {
     gecm_s2_plan s2;
     int s2_ready;
     uint32_t *hacc, *hfail;
+    uint32_t fail_planes;    /* planes of hfail: 1, or 1 + sub-sequences (gecm_dev_s2_fail_planes) */
+    gecm_pairs pm;           /* pair map of the last single-range gecm_stage2 call (pm_valid), reused while (range, D, U) match */
+    int pm_valid;
+    uint64_t pm_lo, pm_hi;
+    uint32_t pm_D, pm_U;
     int have_acc;
     uint32_t *flags[2];      /* per-curve result of the last device factor scan: stage 1, stage 2 */
     uint32_t *hg[2];         /* and the gcds it computed, [nl][batch] */
@@ -292,6 +297,7 @@ void gecm_destroy(gecm_ctx *c)
     gecm_tape_free(&c->tape);
     free_batch(c);
     gecm_s2_plan_free(&c->s2);
+    if (c->pm_valid) gecm_pairmap_release(&c->pm);
     free(c->r3_28);
     free(c->n28);
     free(c);
@@ -406,6 +412,7 @@ static int alloc_batch(gecm_ctx *c, size_t batch)
     c->hz = (uint32_t *)calloc(batch * (size_t)c->nl, 4);
     c->hacc = (uint32_t *)calloc(batch * (size_t)c->nl, 4);
     c->hfail = (uint32_t *)calloc(batch * (size_t)c->nl, 4);
+    c->fail_planes = 1;
     if (!c->sigma || !c->bad || !c->hx || !c->hz || !c->hacc || !c->hfail) { free_batch(c); return GECM_ERR_NOMEM; }
     c->batch = batch;
     if (gecm_dev_resize(c->dev, batch)) { set_err("%s", gecm_dev_error()); return GECM_ERR_DEVICE; }
@@ -919,9 +926,35 @@ int gecm_stage2_init(gecm_ctx *c, uint32_t D, uint32_t U)
     c->s2_numinv = 1;                                        /* ecm.c:2322 */
     c->s2_devinv = (c->s2.npb - 1 + GECM_S2_BLK - 1) / GECM_S2_BLK;
     c->s2_paired = 0;
-    if (gecm_dev_s2_init(c->dev, c->s2.keep, c->s2.keep_words, c->s2.umax, D, c->s2.npb, S2_GIANT_CHUNK, S2_RING)) {
+    /* small batches: K interleaved sub-sequences per curve (csrc/gecm_stage2.hpp, s2_init_k): the table indices of
+     * the kept members of sub-sequence r, j = r, r+K, ... (r = 0: K, 2K, ...), in order */
+    const uint32_t K = gecm_dev_s2_subseq(c->dev);
+    uint32_t *tgt = NULL, toff[33];
+    memset(toff, 0, sizeof toff);
+    if (K > 1) {
+        tgt = (uint32_t *)malloc(((size_t)c->s2.npb + 1) * sizeof(uint32_t));
+        if (!tgt) return GECM_ERR_NOMEM;
+        uint32_t n = 0;
+        for (uint32_t r = 0; r < K; r++) {
+            toff[r] = n;
+            for (uint32_t j = r ? r : K; j <= c->s2.umax; j += K)
+                if (c->s2.map[j]) tgt[n++] = c->s2.map[j];
+        }
+        toff[K] = n;
+    }
+    const uint32_t planes_before = c->fail_planes;
+    int drc = gecm_dev_s2_init(c->dev, c->s2.keep, c->s2.keep_words, c->s2.umax, D, c->s2.npb, S2_GIANT_CHUNK, S2_RING, tgt,
+                               toff, K);
+    free(tgt);
+    if (drc) {
         set_err("gecm_stage2_init: %s", gecm_dev_error());
         return GECM_ERR_DEVICE;
+    }
+    c->fail_planes = gecm_dev_s2_fail_planes(c->dev);
+    if (c->fail_planes != planes_before || !c->hfail) {
+        free(c->hfail);
+        c->hfail = (uint32_t *)calloc(c->batch * (size_t)c->nl * c->fail_planes, 4);
+        if (!c->hfail) return GECM_ERR_NOMEM;
     }
     c->s2_ready = 1;
     return GECM_OK;
@@ -984,7 +1017,11 @@ int gecm_stage2_pair(gecm_ctx *c, uint32_t steps, const uint32_t *pm_v, const ui
     while (generated < (upto)) {                                                                     \
         const uint64_t lim = generated < g0 ? g0 : E;                                                \
         const uint64_t n = lim - generated < S2_GIANT_CHUNK ? lim - generated : S2_GIANT_CHUNK;      \
-        tape[nt++] = 0xffffffffu; tape[nt++] = (uint32_t)n; generated += n; devinv++;                \
+        /* bit 31: one chain, one inversion (csrc/gecm_kernels.hip) — the reference's last batch, and every chunk \
+         * of a range that starts at amin = 0 (B1 < D: the reference's first giant steps are then [0]Q and a ladder \
+         * with a negative multiplier, reproduced as they are by the plain chain only) */ \
+        tape[nt++] = 0xffffffffu; tape[nt++] = (uint32_t)n | ((generated >= g0 || amin == 0) ? 0x80000000u : 0u);   \
+        generated += n; devinv++;                                                                    \
     }
     NEED(2ull * p->L);
     for (uint32_t i = 0; i < steps; i++) {
@@ -1036,11 +1073,25 @@ int gecm_stage2(gecm_ctx *c, uint64_t B2, uint32_t D, uint32_t U)
     if (rc) return rc;
     for (uint64_t p = c->B1; p < B2; p += PRIME_RANGE) {                 /* ecm.c:1424-1476 */
         uint64_t hi = p + PRIME_RANGE < B2 ? p + PRIME_RANGE : B2;
+        /* the pair map depends on (range, D, U) only: a run of many batches (the reference: one per 8 curves and
+         * thread) computes it once; the last single-range map is kept in the context */
+        const int cacheable = (p == c->B1 && hi == B2);
+        if (cacheable && c->pm_valid && c->pm_lo == p && c->pm_hi == hi && c->pm_D == c->s2.D && c->pm_U == c->s2.U) {
+            rc = gecm_stage2_pair(c, c->pm.steps, c->pm.pairmap_v, c->pm.pairmap_u, c->pm.amin);
+            if (rc) return rc;
+            continue;
+        }
         gecm_pairs pm;
         rc = gecm_pair_primes(&pm, p, hi, c->s2.D, c->s2.U);
         if (rc) return rc;
         rc = gecm_stage2_pair(c, pm.steps, pm.pairmap_v, pm.pairmap_u, pm.amin);
-        gecm_pairmap_release(&pm);
+        if (cacheable && !rc) {
+            if (c->pm_valid) gecm_pairmap_release(&c->pm);
+            c->pm = pm;
+            c->pm_valid = 1; c->pm_lo = p; c->pm_hi = hi; c->pm_D = c->s2.D; c->pm_U = c->s2.U;
+        } else {
+            gecm_pairmap_release(&pm);
+        }
         if (rc) return rc;
     }
     return gecm_sync(c);
@@ -1064,6 +1115,26 @@ static int fetch_acc(gecm_ctx *c)
     return GECM_OK;
 }
 
+/* The failed-inversion record of curve k: plane 0 (the single-chain inversions; after gecm_stage2_pair the
+ * reference's last batch of the range) if it holds one, else the gcd of N with the product of the sub-sequences'
+ * records (a curve whose inversions fail only here and there). */
+static void fail_record(gecm_ctx *c, size_t k, mpl_t *g)
+{
+    const size_t plane = c->batch * (size_t)c->nl;
+    mpl_from_limbs32(g, c->hfail + k, c->batch, c->nl, LIMB_BITS);
+    if (!mpl_is_zero(g) || c->fail_planes <= 1) return;
+    mpl_t prod, t;
+    mpl_set_u64(&prod, 0);
+    for (uint32_t p = 1; p < c->fail_planes; p++) {
+        mpl_from_limbs32(&t, c->hfail + p * plane + k, c->batch, c->nl, LIMB_BITS);
+        if (mpl_is_zero(&t)) continue;
+        if (mpl_is_zero(&prod)) prod = t;
+        else mpl_mulmod(&prod, &prod, &t, &c->N);
+        if (mpl_is_zero(&prod)) { prod = c->N; break; }       /* the product covers N: gcd = N, "no factor" */
+    }
+    if (!mpl_is_zero(&prod)) mpl_gcd(g, &prod, &c->N);
+}
+
 int gecm_download_acc(gecm_ctx *c, void *acc)
 {
     if (!c || !acc) return GECM_ERR_ARG;
@@ -1084,7 +1155,7 @@ int gecm_stage2_factor(gecm_ctx *c, size_t k, char *dec, size_t declen, int *is_
     int rc = fetch_acc(c);
     if (rc) return rc;
     mpl_t a, g;
-    mpl_from_limbs32(&g, c->hfail + k, c->batch, c->nl, LIMB_BITS);
+    fail_record(c, k, &g);
     if (mpl_is_zero(&g)) {
         if (c->scan_valid[1] && c->hg[1]) {
             mpl_from_limbs32(&g, c->hg[1] + k, c->batch, c->nl, LIMB_BITS);
@@ -1124,7 +1195,7 @@ int gecm_scan_factors(gecm_ctx *c, int stage, size_t *first)
         if (rc) return rc;
         for (size_t k = 0; k < c->batch; k++) {
             mpl_t g;
-            mpl_from_limbs32(&g, c->hfail + k, c->batch, c->nl, LIMB_BITS);
+            fail_record(c, k, &g);
             if (!mpl_is_zero(&g)) (*f)[k] = (mpl_cmp_u64(&g, 1) > 0 && mpl_cmp(&g, &c->N) != 0);
         }
     }

@@ -153,6 +153,29 @@ def test_stage2_config1_lane_with_stage1_factor():
     _kat("config1_fib791", lanes=8)
 
 
+@pytest.mark.parametrize("args", [(200, 200, 60000, 210, 4), (130, 2000, 100000, 385, 16), (70, 5000, 300000, 2310, 3)])
+def test_stage2_sub_sequences_give_the_plain_chain_s_accumulators(args):
+    """small batches build the table and make the giant steps with K interleaved sub-sequences per curve
+    (gecm_dev_s2_subseq; GECM_S2_SUBSEQ overrides): same points, same X/Z, same accumulator as the plain chain, for
+    every K; B1 < D (amin = 0, where the reference's first giant steps are degenerate) falls back to the plain chain"""
+    import pyecm
+    batch, b1, b2, D, U = args
+    sig = list(range(5000, 5000 + batch))
+    accs = {}
+    for K in (1, 2, 8, 32):
+        os.environ["GECM_S2_SUBSEQ"] = str(K)
+        try:
+            eng = pyecm.Engine(K1N)
+            eng.build_curves(sig)
+            eng.stage1(b1)
+            eng.stage2(b2, D, U)
+            accs[K] = eng.download_acc()
+            eng.close()
+        finally:
+            os.environ.pop("GECM_S2_SUBSEQ", None)
+    assert accs[2] == accs[1] and accs[8] == accs[1] and accs[32] == accs[1]
+
+
 def test_stage2_rejects_table_height_beyond_the_ring():
     import pyecm
     eng = pyecm.Engine(K1N)
