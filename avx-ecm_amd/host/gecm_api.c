@@ -978,88 +978,26 @@ void gecm_pairmap_release(gecm_pairs *p)
     memset(p, 0, sizeof *p);
 }
 
-static int cmp_pair_slot(const void *a, const void *b)
-{
-    const uint32_t *x = (const uint32_t *)a, *y = (const uint32_t *)b;
-    if (x[0] != y[0]) return x[0] < y[0] ? -1 : 1;
-    return x[1] < y[1] ? -1 : (x[1] > y[1]);
-}
-
 int gecm_stage2_pair(gecm_ctx *c, uint32_t steps, const uint32_t *pm_v, const uint32_t *pm_u, uint32_t amin)
 {
     if (!c || !c->s2_ready) { set_err("gecm_stage2_pair: gecm_stage2_init has not run"); return GECM_ERR_STATE; }
     if (steps && (!pm_v || !pm_u)) return GECM_ERR_ARG;
     const gecm_s2_plan *p = &c->s2;
-    /* Resolve the map on the host.  A pair (v,u) refers to giant step number 2*amin_now + (v - amin_now)
-     * counted from [A0]Q in steps of D (ecm.c:2378, 2505) and to table entry map[u].  The device makes
-     * giant steps in chunks of S2_GIANT_CHUNK (one inversion each, csrc/gecm_stage2.hpp) into a ring, so
-     * the tape carries ring slots and "generate n more" marks; the reference's counters (one batch
-     * of 2U new steps and one inversion per window shift) are kept for the statistics. */
-    /* The reference makes E = 2L + 2U * (window shifts) giant steps in this range and inverts them in batches:
-     * the first 2L together, then the 2U new ones of every shift (ecm.c:2425, 2499).  The device chunks never go
-     * beyond E, and the last chunk is exactly the reference's last batch [g0, E): when a curve's inversions fail
-     * (it found its factor already: every Z is 0 modulo it), the gcd the reference's accumulator ends up carrying
-     * is the one of its last failing batch (ecm.c:1925-1939 overwrites stg2acc each time), and the device's record
-     * (fe_inv_mont: the last failure wins) is then taken over the same points. */
-    uint64_t shifts = 0;
-    for (uint32_t i = 0; i < steps; i++) shifts += (pm_v[i] == 0 && pm_u[i] == 0);
-    const uint64_t E = 2ull * p->L + 2ull * p->U * shifts;
-    const uint64_t g0 = shifts ? E - 2ull * p->U : 0;
-    const size_t max_marks = (size_t)(E / S2_GIANT_CHUNK) + 4;
-    uint32_t *tape = (uint32_t *)malloc(((size_t)steps + max_marks) * 2 * sizeof(uint32_t));
-    if (!tape) return GECM_ERR_NOMEM;
-    size_t nt = 0;
-    uint32_t run_amin = amin;
-    uint64_t adds = 2ull * p->L - 1, inv = 2, paired = 0, devinv = 0;   /* ecm.c:2401-2429 */
-    uint64_t generated = 0;                      /* giant steps the device will have made so far */
-    const uint64_t base = 2ull * amin;           /* absolute number of giant step 0 (in units of D) */
-#define NEED(upto)                                                                                   \
-    while (generated < (upto)) {                                                                     \
-        const uint64_t lim = generated < g0 ? g0 : E;                                                \
-        const uint64_t n = lim - generated < S2_GIANT_CHUNK ? lim - generated : S2_GIANT_CHUNK;      \
-        /* bit 31: one chain, one inversion (csrc/gecm_kernels.hip) — the reference's last batch, and every chunk \
-         * of a range that starts at amin = 0 (B1 < D: the reference's first giant steps are then [0]Q and a ladder \
-         * with a negative multiplier, reproduced as they are by the plain chain only) */ \
-        tape[nt++] = 0xffffffffu; tape[nt++] = (uint32_t)n | ((generated >= g0 || amin == 0) ? 0x80000000u : 0u);   \
-        generated += n; devinv++;                                                                    \
-    }
-    NEED(2ull * p->L);
-    for (uint32_t i = 0; i < steps; i++) {
-        if (pm_v[i] == 0 && pm_u[i] == 0) {
-            run_amin += p->U;                                            /* ecm.c:2496 */
-            adds += 2ull * p->U; inv++;
-            NEED(2ull * run_amin - base + 2ull * p->L);
-        } else {
-            uint32_t pa = pm_v[i] - run_amin, pb = pm_u[i];
-            if (pa >= 2 * p->L || pb > p->umax || p->map[pb] == 0) {     /* ecm.c:2508-2517 */
-                free(tape);
-                set_err("gecm_stage2_pair: invalid pair map entry %u: (%u,%u) amin %u", i, pm_v[i], pm_u[i], run_amin);
-                return GECM_ERR_ARG;
-            }
-            uint64_t absidx = 2ull * run_amin - base + pa;
-            tape[nt++] = (uint32_t)(absidx & (S2_RING - 1));
-            tape[nt++] = p->map[pb];
-            paired++;
-        }
-    }
-#undef NEED
-    /* Within a segment (between two "generate" marks) the accumulator is a plain product, so the
-     * pairs may be taken in any order: sort them by giant step so the device re-reads a ring row only
-     * when it changes (csrc/gecm_stage2.hpp, s2_pairs). */
-    for (size_t i = 0; i < nt;) {
-        if (tape[i] == 0xffffffffu) { i += 2; continue; }
-        size_t j = i;
-        while (j < nt && tape[j] != 0xffffffffu) j += 2;
-        qsort(tape + i, (j - i) / 2, 2 * sizeof(uint32_t), cmp_pair_slot);
-        i = j;
+    gecm_s2_tape t;
+    uint32_t bad = 0;
+    int trc = gecm_s2_tape_build(&t, p, steps, pm_v, pm_u, amin, S2_GIANT_CHUNK, S2_RING, &bad);
+    if (trc == -1) return GECM_ERR_NOMEM;
+    if (trc) {                                                           /* ecm.c:2508-2517 */
+        set_err("gecm_stage2_pair: invalid pair map entry %u: (%u,%u)", bad, pm_v[bad], pm_u[bad]);
+        return GECM_ERR_ARG;
     }
     uint64_t A0 = (uint64_t)amin * p->D * 2;                             /* ecm.c:2378 */
-    adds += ladder_adds(A0) + ladder_adds(A0 - p->D);                    /* ecm.c:2383, 2390 */
-    int rc = gecm_dev_s2_pair(c->dev, tape, (uint32_t)(nt / 2), p->D, S2_GIANT_CHUNK, S2_RING, A0);
-    free(tape);
+    t.adds += ladder_adds(A0) + ladder_adds(A0 - p->D);                  /* ecm.c:2383, 2390 */
+    int rc = gecm_dev_s2_pair(c->dev, t.words, (uint32_t)(t.nwords / 2), p->D, S2_GIANT_CHUNK, S2_RING, A0);
+    free(t.words);
     if (rc) { set_err("gecm_stage2_pair: %s", gecm_dev_error()); return GECM_ERR_DEVICE; }
-    c->s2_ptadds += adds; c->s2_numinv += inv; c->s2_paired += paired; c->s2_devinv += devinv;
-    c->s2_amin_last = run_amin;
+    c->s2_ptadds += t.adds; c->s2_numinv += t.inv; c->s2_paired += t.paired; c->s2_devinv += t.devinv;
+    c->s2_amin_last = t.amin_last;
     c->have_acc = 0;
     c->scan_valid[1] = 0;
     return GECM_OK;

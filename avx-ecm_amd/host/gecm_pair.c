@@ -194,3 +194,73 @@ void gecm_pairmap_free(gecm_pairmap *pm)
     free(pm->u);
     memset(pm, 0, sizeof *pm);
 }
+
+/* ---- the device tape of one range (see gecm_pair.h) ---------------------------------------------------------- */
+static int cmp_pair_slot(const void *a, const void *b)
+{
+    const uint32_t *x = (const uint32_t *)a, *y = (const uint32_t *)b;
+    if (x[0] != y[0]) return x[0] < y[0] ? -1 : 1;
+    return x[1] < y[1] ? -1 : (x[1] > y[1]);
+}
+
+int gecm_s2_tape_build(gecm_s2_tape *out, const gecm_s2_plan *p, uint32_t steps, const uint32_t *pm_v, const uint32_t *pm_u,
+                       uint32_t amin, uint32_t chunk, uint32_t ring, uint32_t *bad)
+{
+    memset(out, 0, sizeof *out);
+    if (bad) *bad = 0;
+    if (!chunk || (ring & (ring - 1)) || 4ull * p->U + chunk > ring) return -2;
+    uint64_t shifts = 0;
+    for (uint32_t i = 0; i < steps; i++) shifts += (pm_v[i] == 0 && pm_u[i] == 0);
+    const uint64_t E = 2ull * p->L + 2ull * p->U * shifts;
+    const uint64_t g0 = shifts ? E - 2ull * p->U : 0;
+    /* marks: ceil(g0 / chunk) + ceil((E - g0) / chunk), each one pair of words */
+    const size_t max_marks = (size_t)(g0 / chunk) + (size_t)((E - g0) / chunk) + 4;
+    uint32_t *tape = (uint32_t *)malloc(((size_t)steps + max_marks) * 2 * sizeof(uint32_t));
+    if (!tape) return -1;
+    const size_t cap = ((size_t)steps + max_marks) * 2;
+    size_t nt = 0;
+    uint32_t run_amin = amin;
+    uint64_t adds = 2ull * p->L - 1, inv = 2, paired = 0, devinv = 0;    /* ecm.c:2401-2429 */
+    uint64_t generated = 0;                      /* giant steps the device will have made so far */
+    const uint64_t base = 2ull * amin;           /* absolute number of giant step 0 (in units of D) */
+#define NEED(upto)                                                                                       \
+    while (generated < (upto)) {                                                                         \
+        const uint64_t lim = generated < g0 ? g0 : E;                                                    \
+        const uint64_t n = lim - generated < chunk ? lim - generated : chunk;                            \
+        if (nt + 2 > cap) { free(tape); return -1; }                                                     \
+        tape[nt++] = GECM_S2_GEN;                                                                        \
+        tape[nt++] = (uint32_t)n | ((generated >= g0 || amin == 0) ? 0x80000000u : 0u);                  \
+        generated += n; devinv++;                                                                        \
+    }
+    NEED(2ull * p->L);
+    for (uint32_t i = 0; i < steps; i++) {
+        if (pm_v[i] == 0 && pm_u[i] == 0) {
+            run_amin += p->U;                                            /* ecm.c:2496 */
+            adds += 2ull * p->U; inv++;
+            NEED(2ull * run_amin - base + 2ull * p->L);
+        } else {
+            const uint32_t pa = pm_v[i] - run_amin, pb = pm_u[i];
+            if (pm_v[i] < run_amin || pa >= 2 * p->L || pb > p->umax || p->map[pb] == 0) {     /* ecm.c:2508-2517 */
+                free(tape);
+                if (bad) *bad = i;
+                return -2;
+            }
+            const uint64_t absidx = 2ull * run_amin - base + pa;
+            if (nt + 2 > cap) { free(tape); return -1; }
+            tape[nt++] = (uint32_t)(absidx & (ring - 1));
+            tape[nt++] = p->map[pb];
+            paired++;
+        }
+    }
+#undef NEED
+    for (size_t i = 0; i < nt;) {
+        if (tape[i] == GECM_S2_GEN) { i += 2; continue; }
+        size_t j = i;
+        while (j < nt && tape[j] != GECM_S2_GEN) j += 2;
+        qsort(tape + i, (j - i) / 2, 2 * sizeof(uint32_t), cmp_pair_slot);
+        i = j;
+    }
+    out->words = tape; out->nwords = nt;
+    out->adds = adds; out->inv = inv; out->paired = paired; out->devinv = devinv; out->amin_last = run_amin;
+    return 0;
+}

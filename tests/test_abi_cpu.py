@@ -217,3 +217,73 @@ def test_input_expression_evaluator(lib):
     assert ev("1<<100") == 1 << 100 and ev("(2^200+5)>>3") == (2 ** 200 + 5) >> 3
     for bad in ("3-5", "1/0", "foo(3)", "2^100000", "(1+2", "", "modinv(2,4)"):
         assert ev(bad) is None
+
+
+def test_stage2_device_tape_follows_the_reference_s_batches(lib):
+    """gecm_s2_tape_build (host/gecm_pair.c): the giant steps the tape asks for are exactly the reference's E = 2L + 2U
+    per window shift (ecm.c:2425, 2499), no chunk exceeds 512, the LAST chunk is the reference's last inversion batch
+    (its 2U newest steps) and is flagged single-chain, every pair lands on the giant step and table entry its (v,u)
+    names, and a table too tall for the ring, or an entry outside the window, is refused"""
+    import pyecm
+
+    class Plan(ctypes.Structure):
+        _fields_ = [("D", ctypes.c_uint32), ("U", ctypes.c_uint32), ("L", ctypes.c_uint32), ("R", ctypes.c_uint32),
+                    ("umax", ctypes.c_uint32), ("map", ctypes.POINTER(ctypes.c_uint32)), ("npb", ctypes.c_uint32),
+                    ("keep", ctypes.POINTER(ctypes.c_uint32)), ("keep_words", ctypes.c_size_t)]
+
+    class Tape(ctypes.Structure):
+        _fields_ = [("words", ctypes.POINTER(ctypes.c_uint32)), ("nwords", ctypes.c_size_t), ("adds", ctypes.c_uint64),
+                    ("inv", ctypes.c_uint64), ("paired", ctypes.c_uint64), ("devinv", ctypes.c_uint64),
+                    ("amin_last", ctypes.c_uint32)]
+
+    PU = ctypes.POINTER(ctypes.c_uint32)
+    lib.gecm_s2_plan_init.argtypes = [ctypes.POINTER(Plan), ctypes.c_uint32, ctypes.c_uint32]
+    lib.gecm_s2_plan_free.argtypes = [ctypes.POINTER(Plan)]
+    lib.gecm_s2_tape_build.argtypes = [ctypes.POINTER(Tape), ctypes.POINTER(Plan), ctypes.c_uint32, PU, PU, ctypes.c_uint32,
+                                       ctypes.c_uint32, ctypes.c_uint32, PU]
+    libc = ctypes.CDLL(None)
+    libc.free.argtypes = [ctypes.c_void_p]
+    GEN, chunk, ring = 0xffffffff, 512, 1024
+    for b1, b2, D, U in [(10000, 3000000, 2310, 16), (2000, 100000, 385, 4), (300, 20000, 210, 3), (100, 9000, 210, 2)]:
+        plan, tape, bad = Plan(), Tape(), ctypes.c_uint32()
+        assert lib.gecm_s2_plan_init(ctypes.byref(plan), D, U) == 0
+        pm = pyecm.pair_primes(b1, b2, D, U)
+        assert lib.gecm_s2_tape_build(ctypes.byref(tape), ctypes.byref(plan), pm.steps, pm.pairmap_v, pm.pairmap_u, pm.amin,
+                                      chunk, ring, ctypes.byref(bad)) == 0
+        w = [tape.words[i] for i in range(tape.nwords)]
+        shifts = sum(1 for i in range(pm.steps) if pm.pairmap_v[i] == 0 and pm.pairmap_u[i] == 0)
+        E = 4 * U + 2 * U * shifts
+        gens = [(w[i + 1] & 0x7fffffff, w[i + 1] >> 31) for i in range(0, len(w), 2) if w[i] == GEN]
+        assert sum(n for n, f in gens) == E and all(0 < n <= chunk for n, f in gens)
+        assert gens[-1] == ((2 * U if shifts else 4 * U), 1)                 # the reference's last batch, one chain
+        assert all(f == (1 if pm.amin == 0 else 0) for n, f in gens[:-1])    # amin = 0: the plain chain throughout
+        assert (tape.paired, tape.inv, tape.amin_last) == (pm.pairs, 2 + shifts, pm.amin + U * shifts)
+        # replay: every pair must find its giant step generated and still inside the ring
+        want, amin = [], pm.amin
+        for i in range(pm.steps):
+            if pm.pairmap_v[i] == 0 and pm.pairmap_u[i] == 0:
+                amin += U
+            else:
+                want.append(((2 * amin - 2 * pm.amin + pm.pairmap_v[i] - amin) % ring, plan.map[pm.pairmap_u[i]]))
+        got, generated = [], 0
+        for i in range(0, len(w), 2):
+            if w[i] == GEN:
+                generated += w[i + 1] & 0x7fffffff
+            else:
+                got.append((w[i], w[i + 1]))
+        assert sorted(got) == sorted(want) and generated == E
+        libc.free(tape.words)
+        # one entry outside the window: refused with its index
+        v = (ctypes.c_uint32 * 3)(pm.pairmap_v[0], pm.amin + 4 * U, pm.pairmap_v[0])
+        u = (ctypes.c_uint32 * 3)(pm.pairmap_u[0], pm.pairmap_u[0], pm.pairmap_u[0])
+        assert lib.gecm_s2_tape_build(ctypes.byref(tape), ctypes.byref(plan), 3, v, u, pm.amin, chunk, ring, ctypes.byref(bad)) == -2
+        assert bad.value == 1
+        lib.gecm_pairmap_release(ctypes.byref(pm))
+        lib.gecm_s2_plan_free(ctypes.byref(plan))
+    # a table taller than the ring allows (4U + chunk > ring)
+    plan = Plan()
+    assert lib.gecm_s2_plan_init(ctypes.byref(plan), 210, 129) == 0
+    z = (ctypes.c_uint32 * 4)(0, 0, 0, 0)
+    tape, bad = Tape(), ctypes.c_uint32()
+    assert lib.gecm_s2_tape_build(ctypes.byref(tape), ctypes.byref(plan), 4, z, z, 5, chunk, ring, ctypes.byref(bad)) == -2
+    lib.gecm_s2_plan_free(ctypes.byref(plan))

@@ -92,6 +92,51 @@ int main(void)
             if (!rc) gecm_pairmap_free(&pm);
             gecm_s2_plan_free(&p);
         }
+    /* 5. the device tape of a range: real pair maps, then hostile ones (nothing but window shifts with a tall table —
+     * the case that overran a fixed-size tape in round 1 —, random entries, a table too tall for the ring) */
+    {
+        const uint32_t chunk = 512, ring = 1024;
+        for (uint32_t U = 2; U <= 256; U *= 2) {
+            gecm_s2_plan p;
+            if (gecm_s2_plan_init(&p, 210, U)) continue;
+            gecm_pairmap pm;
+            gecm_s2_tape t;
+            uint32_t bad = 0;
+            if (!gecm_pair(&pm, 1000, 200000, 210, U)) {
+                int rc = gecm_s2_tape_build(&t, &p, pm.steps, pm.v, pm.u, pm.amin, chunk, ring, &bad);
+                uint64_t gen = 0, pairs = 0;
+                if (!rc) {
+                    for (size_t i = 0; i < t.nwords; i += 2)
+                        if (t.words[i] == GECM_S2_GEN) gen += t.words[i + 1] & 0x7fffffffu; else pairs++;
+                    if (pairs != pm.pairs || pairs != t.paired) { printf("tape: pair count mismatch\n"); return 1; }
+                    free(t.words);
+                }
+                printf("tape U=%u rc=%d steps=%u marks+pairs=%zu giant steps=%lu\n", U, rc, pm.steps, rc ? 0 : t.nwords / 2,
+                       (unsigned long)gen);
+                gecm_pairmap_free(&pm);
+            }
+            /* 5000 window shifts and nothing else */
+            uint32_t *z = (uint32_t *)calloc(5000, sizeof(uint32_t));
+            int rc = gecm_s2_tape_build(&t, &p, 5000, z, z, 7, chunk, ring, &bad);
+            if (!rc) {
+                uint64_t gen = 0;
+                for (size_t i = 0; i < t.nwords; i += 2) gen += t.words[i + 1] & 0x7fffffffu;
+                if (gen != 2ull * p.L + 2ull * U * 5000) { printf("tape: wrong number of giant steps\n"); return 1; }
+                if (!(t.words[t.nwords - 1] & 0x80000000u)) { printf("tape: last chunk not flagged\n"); return 1; }
+                free(t.words);
+            }
+            printf("tape U=%u all-shifts rc=%d\n", U, rc);
+            /* random entries: refused with the index of the first bad one, never a crash */
+            for (int it = 0; it < 200; it++) {
+                uint32_t v[64], u[64];
+                for (int i = 0; i < 64; i++) { v[i] = (uint32_t)(rnd() % 40); u[i] = (uint32_t)(rnd() % (p.umax + 50)); }
+                rc = gecm_s2_tape_build(&t, &p, 64, v, u, (uint32_t)(rnd() % 8), chunk, ring, &bad);
+                if (!rc) free(t.words);
+            }
+            free(z);
+            gecm_s2_plan_free(&p);
+        }
+    }
     size_t np;
     uint64_t *pr = gecm_primes_range(999999000ull, 1000001000ull, &np);
     printf("primes in [999999000, 1000001000): %zu\n", np);
