@@ -62,7 +62,7 @@ int gecm_dev_l0(gecm_dev *d, int op, const uint32_t *a, const uint32_t *b, uint3
                 size_t count, const uint32_t *fix);
 
 /* ---- stage 2 (csrc/gecm_stage2.hpp) ----
- * r3 = R^3 mod N (28-bit limbs); inv_iters = iteration count of the device inversion. */
+ * r3 = R^3 mod N (28-bit limbs); inv_iters = batches of 28 division steps of the device inversion (fe_invert). */
 int gecm_dev_set_s2const(gecm_dev *d, const uint32_t *r3, uint32_t inv_iters);
 /* ecm_stage2_init: baby-step table (npb entries, X/Z normalised), Pd = [D]Q, acc = one.
  * keep: bitmap over j in [0, umax], bit set iff j is stored.  L = ring half-size (2L giant steps). */

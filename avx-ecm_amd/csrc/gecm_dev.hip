@@ -457,9 +457,8 @@ extern "C" size_t gecm_dev_s2_bytes(int nl, size_t ncurves, uint32_t npb, uint32
  * GECM_S2_SUBSEQ=1..32 (a power of two) overrides, for measurements. */
 extern "C" uint32_t gecm_dev_s2_subseq(gecm_dev *d)
 {
-    // one wavefront per SIMD is the target: every sub-sequence pays one inversion per chunk (about as much as a
-    // thousand multiplications), and at 4096 curves K = 16 measured 0.73 s for B2 = 1e8 against 0.79 s with K = 32
-    const size_t waves = d->stride / 64, want = (size_t)d->cus * 4;
+    // two wavefronts per SIMD is the target (4096 curves, B2 = 1e8: K = 1 1.14 s, 4 0.75 s, 16 and 32 0.64 s)
+    const size_t waves = d->stride / 64, want = (size_t)d->cus * 4 * 2;
     uint32_t k = 1;
     while (k < 32 && waves * (k * 2) <= want) k *= 2;
     if (const char *e = getenv("GECM_S2_SUBSEQ")) {

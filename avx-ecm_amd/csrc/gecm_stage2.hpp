@@ -31,7 +31,7 @@ struct S2Const {
     ModK<NL> m;
     Fe<NL> one;   // R mod N
     Fe<NL> r3;    // R^3 mod N  (plain inverse -> Montgomery form of the inverse)
-    uint32_t inv_iters;   // 2 * bitlen(N)
+    uint32_t inv_iters;   // batches of 28 division steps of the inversion (fe_invert)
 };
 
 // Tables are tiled per wavefront: [wave][entry][limb][lane].  One entry of one wave is NL*256
@@ -105,59 +105,130 @@ __device__ __forceinline__ void fe_select(Fe<NL> &r, bool c, const Fe<NL> &a, co
     for (int i = 0; i < NL; i++) r.v[i] = c ? a.v[i] : b.v[i];
 }
 
-// x^-1 mod N for canonical x (plain integers, not Montgomery form), fixed iteration count
-// (branch-free per lane).  Invariants: x1*x = u, x2*x = v (mod N); v stays odd; at the end u = 0
-// and v = gcd(x, N).  Returns true iff the inverse exists; g receives the gcd.
-template <int NL>
-__device__ __noinline__ bool fe_invert(Fe<NL> &r, Fe<NL> &g, const Fe<NL> &x, const ModK<NL> &m, uint32_t iters)
+// x^-1 mod N for canonical x (plain integers, not Montgomery form) and gcd(x, N), in a fixed number of steps
+// (branch-free per lane).  Bernstein-Yang division steps in the batched form of libsecp256k1's modinv32, on 28-bit
+// limbs: a batch runs 28 division steps on the low words of (f, g) = (N, x) with cheap 32-bit instructions and
+// yields a 2x2 transition matrix (entries below 2^28 in size), which is then applied to the full (f, g) and — modulo
+// N, with the exact division by 2^28 done the Montgomery way — to the cofactors (d, e), d*x = f, e*x = g (mod N),
+// with v_mad_i64_i32 rows.  After `batches` >= ceil((floor((45907 bits + 26313) / 19929) + 1) / 28) batches (the
+// published bound for the "half-delta" variant) g = 0 and f = +-gcd(x, N).  About 26k instructions at 15 limbs where
+// the bit-by-bit binary inversion this replaces took 500k (one inversion cost as much as a thousand multiplications;
+// tools/s2_subseq_check.py history in DESIGN.md §7).  Returns true iff the inverse exists; g receives the gcd.
+__device__ __forceinline__ void imad(int64_t &acc, int32_t x, int32_t y)
 {
-    Fe<NL> u = x, v, x1, x2, n;
+    asm("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(x), "v"(y) : "vcc");
+}
+
+template <int NL>
+__device__ __noinline__ bool fe_invert(Fe<NL> &r, Fe<NL> &gout, const Fe<NL> &x, const ModK<NL> &m, uint32_t batches)
+{
+    constexpr int32_t M28 = (int32_t)GECM_LIMB_MASK;
+    int32_t f[NL], g[NL], d[NL], e[NL];     // low limbs in [0, 2^28), the top limb carries the sign
 #pragma unroll
     for (int i = 0; i < NL; i++) {
-        v.v[i] = m.n[i];
-        n.v[i] = m.n[i];
-        x1.v[i] = (i == 0) ? 1u : 0u;
-        x2.v[i] = 0u;
+        f[i] = (int32_t)m.n[i];
+        g[i] = (int32_t)x.v[i];
+        d[i] = 0;
+        e[i] = (i == 0) ? 1 : 0;
     }
-    for (uint32_t it = 0; it < iters; it++) {
-        bool odd = (u.v[0] & 1u) != 0;
-        Fe<NL> d, e, t, tn;
-        uint32_t lt = fe_sub_borrow(d, u, v);      // d = u - v
-        fe_sub_borrow(e, v, u);                     // e = v - u
-        bool sw = odd && lt;
-        uint32_t bt = fe_sub_borrow(t, x1, x2);    // t = x1 - x2 mod N
-        fe_add_carry(tn, t, m.n);
-        tn.v[NL - 1] &= GECM_LIMB_MASK;             // wrapped sum (only used when bt)
-        fe_select(t, bt != 0, tn, t);
-        // negation of t mod N for the swapped case: N - t (t != 0) or 0
-        Fe<NL> nt;
-        fe_sub_borrow(nt, n, t);
-        bool tz = true;
+    const uint32_t ninv = (0u - m.rho) & GECM_LIMB_MASK;        // N^-1 mod 2^28
+    int32_t zeta = -1;
+    for (uint32_t bt = 0; bt < batches; bt++) {
+        // 28 division steps on the low words
+        uint32_t u = 1, v = 0, q = 0, w = 1, fl = (uint32_t)f[0], gl = (uint32_t)g[0];
 #pragma unroll
-        for (int i = 0; i < NL; i++) tz = tz && (t.v[i] == 0);
-        fe_select(nt, tz, t, nt);
-        // apply
-        Fe<NL> nu, nv, nx1, nx2;
-        fe_select(nu, sw, e, d);          // u - v or v - u
-        fe_select(nu, odd, nu, u);
-        fe_select(nv, sw, u, v);
-        fe_select(nx1, sw, nt, t);
-        fe_select(nx1, odd, nx1, x1);
-        fe_select(nx2, sw, x1, x2);
-        u = nu; v = nv; x1 = nx1; x2 = nx2;
-        // halve u, halve x1 mod N
-        fe_shr1(u);
-        Fe<NL> xo;
-        fe_add_carry(xo, x1, m.n);
-        bool xodd = (x1.v[0] & 1u) != 0;
-        fe_select(x1, xodd, xo, x1);
-        fe_shr1(x1);
+        for (int i = 0; i < GECM_LIMB_BITS; i++) {
+            uint32_t c1 = (uint32_t)(zeta >> 31);
+            const uint32_t c2 = 0u - (gl & 1u);
+            const uint32_t xx = (fl ^ c1) - c1, yy = (u ^ c1) - c1, zz = (v ^ c1) - c1;
+            gl += xx & c2; q += yy & c2; w += zz & c2;
+            c1 &= c2;
+            zeta = (zeta ^ (int32_t)c1) - 1;
+            fl += gl & c1; u += q & c1; v += w & c1;
+            gl >>= 1; u <<= 1; v <<= 1;
+        }
+        const int32_t U = (int32_t)u, V = (int32_t)v, Q = (int32_t)q, W = (int32_t)w;
+        // (d, e) <- (U d + V e, Q d + W e) / 2^28 mod N
+        {
+            const int32_t sd = d[NL - 1] >> 31, se = e[NL - 1] >> 31;
+            int32_t md = (U & sd) + (V & se), me = (Q & sd) + (W & se);
+            int64_t cd = 0, ce = 0;
+            imad(cd, U, d[0]); imad(cd, V, e[0]);
+            imad(ce, Q, d[0]); imad(ce, W, e[0]);
+            md -= (int32_t)((ninv * (uint32_t)cd + (uint32_t)md) & GECM_LIMB_MASK);
+            me -= (int32_t)((ninv * (uint32_t)ce + (uint32_t)me) & GECM_LIMB_MASK);
+            imad(cd, (int32_t)m.n[0], md);
+            imad(ce, (int32_t)m.n[0], me);
+            cd >>= GECM_LIMB_BITS;
+            ce >>= GECM_LIMB_BITS;
+#pragma unroll
+            for (int i = 1; i < NL; i++) {
+                imad(cd, U, d[i]); imad(cd, V, e[i]); imad(cd, (int32_t)m.n[i], md);
+                imad(ce, Q, d[i]); imad(ce, W, e[i]); imad(ce, (int32_t)m.n[i], me);
+                d[i - 1] = (int32_t)cd & M28; cd >>= GECM_LIMB_BITS;
+                e[i - 1] = (int32_t)ce & M28; ce >>= GECM_LIMB_BITS;
+            }
+            d[NL - 1] = (int32_t)cd;
+            e[NL - 1] = (int32_t)ce;
+        }
+        // (f, g) <- (U f + V g, Q f + W g) / 2^28   (exact)
+        {
+            int64_t cf = 0, cg = 0;
+            imad(cf, U, f[0]); imad(cf, V, g[0]);
+            imad(cg, Q, f[0]); imad(cg, W, g[0]);
+            cf >>= GECM_LIMB_BITS;
+            cg >>= GECM_LIMB_BITS;
+#pragma unroll
+            for (int i = 1; i < NL; i++) {
+                imad(cf, U, f[i]); imad(cf, V, g[i]);
+                imad(cg, Q, f[i]); imad(cg, W, g[i]);
+                f[i - 1] = (int32_t)cf & M28; cf >>= GECM_LIMB_BITS;
+                g[i - 1] = (int32_t)cg & M28; cg >>= GECM_LIMB_BITS;
+            }
+            f[NL - 1] = (int32_t)cf;
+            g[NL - 1] = (int32_t)cg;
+        }
     }
-    g = v;
-    r = x2;
-    bool ok = (v.v[0] == 1u);
+    // f = +-gcd: make it positive, and give d the same sign change; then d into [0, N)
+    const int32_t sf = f[NL - 1] >> 31;
+    auto negate_if = [&](int32_t (&a)[NL], int32_t mask) {
+        int32_t c = mask & 1;
 #pragma unroll
-    for (int i = 1; i < NL; i++) ok = ok && (v.v[i] == 0);
+        for (int i = 0; i < NL - 1; i++) {
+            const int32_t t = ((a[i] ^ mask) & M28) + c;
+            a[i] = t & M28;
+            c = t >> GECM_LIMB_BITS;
+        }
+        a[NL - 1] = (a[NL - 1] ^ mask) + c;
+    };
+    auto add_n_if = [&](int32_t (&a)[NL], int32_t mask) {
+        int32_t c = 0;
+#pragma unroll
+        for (int i = 0; i < NL - 1; i++) {
+            const int32_t t = a[i] + ((int32_t)m.n[i] & mask) + c;
+            a[i] = t & M28;
+            c = t >> GECM_LIMB_BITS;
+        }
+        a[NL - 1] += ((int32_t)m.n[NL - 1] & mask) + c;
+    };
+    negate_if(f, sf);
+    negate_if(d, sf);                         // d in (-2N, 2N)
+    add_n_if(d, d[NL - 1] >> 31);
+    add_n_if(d, d[NL - 1] >> 31);             // d in [0, 2N)
+    Fe<NL> dv, dn;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        dv.v[i] = (uint32_t)d[i];
+        gout.v[i] = (uint32_t)f[i];
+    }
+    Fe<NL> nn;
+#pragma unroll
+    for (int i = 0; i < NL; i++) nn.v[i] = m.n[i];
+    const uint32_t lt = fe_sub_borrow(dn, dv, nn);          // dv - N
+    fe_select(r, lt != 0, dv, dn);
+    bool ok = (gout.v[0] == 1u);
+#pragma unroll
+    for (int i = 1; i < NL; i++) ok = ok && (gout.v[i] == 0);
     return ok;
 }
 

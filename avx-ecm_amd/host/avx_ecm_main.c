@@ -114,12 +114,34 @@ static void *job_stage2_pair(void *p)
     return NULL;
 }
 
-static int run_all(job_t *jobs, int n, void *(*fn)(void *))
+/* the pair map of the first prime range of stage 2 (ecm.c:1441-1443): identical for every batch, GPU and pass, so it
+ * is made once, on the main thread, while the GPUs run the first stage 1 */
+typedef struct {
+    uint64_t lo, hi;
+    uint32_t D, U;
+    gecm_pairs pm;
+    int valid, rc;
+} first_range_t;
+
+static void make_first_range(first_range_t *fr)
+{
+    if (fr->valid) return;
+    fr->rc = gecm_pair_primes(&fr->pm, fr->lo, fr->hi, fr->D, fr->U);
+    fr->valid = fr->rc == 0;
+}
+
+static int run_all(job_t *jobs, int n, void *(*fn)(void *), first_range_t *meanwhile)
 {
     pthread_t th[MAX_GPUS];
-    for (int i = 1; i < n; i++) pthread_create(&th[i], NULL, fn, &jobs[i]);
-    fn(&jobs[0]);
-    for (int i = 1; i < n; i++) pthread_join(th[i], NULL);
+    if (meanwhile) {                         /* every job on a thread of its own, the host work here */
+        for (int i = 0; i < n; i++) pthread_create(&th[i], NULL, fn, &jobs[i]);
+        make_first_range(meanwhile);
+        for (int i = 0; i < n; i++) pthread_join(th[i], NULL);
+    } else {
+        for (int i = 1; i < n; i++) pthread_create(&th[i], NULL, fn, &jobs[i]);
+        fn(&jobs[0]);
+        for (int i = 1; i < n; i++) pthread_join(th[i], NULL);
+    }
     for (int i = 0; i < n; i++)
         if (jobs[i].rc < 0) {
             fprintf(stderr, "GPU %d: %s\n", jobs[i].gpu, jobs[i].err);
@@ -201,6 +223,12 @@ int main(int argc, char **argv)
     printf("Processing in batches of %u primes\n", 100000000u);                  /* main.c:593 */
     printf("Initialization took %1.4f seconds.\n", now() - t_start);              /* main.c:776 */
 
+    first_range_t first_range;
+    memset(&first_range, 0, sizeof first_range);
+    first_range.lo = B1;
+    first_range.hi = B1 + 100000000ULL < B2 ? B1 + 100000000ULL : B2;
+    first_range.D = gecm_s2_default_D(B1);
+    first_range.U = GECM_S2_DEFAULT_U;
     uint64_t lcg = (uint64_t)(t_start * 1e6) * 0x9E3779B97F4A7C15ULL + (uint64_t)getpid();
     int found = 0;
     static char line[16384], fac[4096];
@@ -220,13 +248,14 @@ int main(int argc, char **argv)
             jobs[g].sigma = sig + lo;
             jobs[g].B1 = B1;
             jobs[g].B2 = B2;
+            jobs[g].do_stage2 = do_stage2;
         }
         double t = now();
-        if (run_all(jobs, gpus, job_build)) return 2;
+        if (run_all(jobs, gpus, job_build, NULL)) return 2;
         printf("Building curves took %1.4f seconds.\n", now() - t);              /* ecm.c:1204 */
         printf("Commencing Stage 1 @ prime 2\n");                                /* ecm.c:1233 */
         t = now();
-        if (run_all(jobs, gpus, job_stage1)) return 2;
+        if (run_all(jobs, gpus, job_stage1, do_stage2 ? &first_range : NULL)) return 2;
         gecm_stage1_stats st;
         gecm_get_stage1_stats(jobs[0].ctx, &st);
         printf("\nStage 1 completed at prime %lu with %lu point-adds and %lu point-doubles\n",
@@ -264,7 +293,7 @@ int main(int argc, char **argv)
         fflush(stdout);
         if (do_stage2) {                                                         /* ecm.c:1394-1528 */
             t = now();
-            if (run_all(jobs, gpus, job_stage2)) return 2;                       /* stage-2 init, ecm.c:1401-1421 */
+            if (run_all(jobs, gpus, job_stage2, NULL)) return 2;                 /* stage-2 init, ecm.c:1401-1421 */
             printf("Stage 2 Init took %1.4f seconds\n", now() - t);              /* ecm.c:1421 */
             gecm_stage2_stats s2;
             gecm_get_stage2_stats(jobs[0].ctx, &s2);
@@ -277,15 +306,18 @@ int main(int argc, char **argv)
             for (uint64_t p = B1; p < B2; p += 100000000ULL) {                   /* ecm.c:1424-1476 */
                 const uint64_t hi = p + 100000000ULL < B2 ? p + 100000000ULL : B2;
                 gecm_pairs pm;
+                const int shared = first_range.valid && p == first_range.lo && hi == first_range.hi &&
+                                   s2.D == first_range.D && s2.U == first_range.U;
                 printf("commencing pair on range %lu:%lu\n", (unsigned long)p, (unsigned long)hi);   /* ecm.c:2568 */
-                if (gecm_pair_primes(&pm, p, hi, s2.D, s2.U)) { fprintf(stderr, "%s\n", gecm_last_error()); return 2; }
+                if (shared) pm = first_range.pm;
+                else if (gecm_pair_primes(&pm, p, hi, s2.D, s2.U)) { fprintf(stderr, "%s\n", gecm_last_error()); return 2; }
                 printf("%u pairs found from %u primes (ratio = %1.2f)\n", pm.pairs, pm.primes,
                        pm.primes ? (double)pm.pairs / (double)pm.primes : 0.0);   /* ecm.c:2904-2905 */
                 printf("\ncommencing stage 2 at A=%lu\nw = %u, R = %u, L = %u, U = %d, umax = %u, amin = %u\n",
                        2ul * (unsigned long)pm.amin * s2.D, s2.D, rcount, s2.L, (int)s2.U, s2.U * s2.D, pm.amin);   /* ecm.c:2440-2442 */
                 for (int g = 0; g < gpus; g++) jobs[g].pm = &pm;
-                if (run_all(jobs, gpus, job_stage2_pair)) return 2;
-                gecm_pairmap_release(&pm);
+                if (run_all(jobs, gpus, job_stage2_pair, NULL)) return 2;
+                if (!shared) gecm_pairmap_release(&pm);
                 gecm_get_stage2_stats(jobs[0].ctx, &s2);
                 printf("\nlast amin: %u\n", s2.amin_last);                       /* ecm.c:1462 */
             }
@@ -315,6 +347,7 @@ int main(int argc, char **argv)
         }
         free(sig);
     }
+    if (first_range.valid) gecm_pairmap_release(&first_range.pm);
     for (int g = 0; g < gpus; g++) gecm_destroy(jobs[g].ctx);
     printf("Process took %1.4f seconds.\n", now() - t_start);                    /* ecm.c:1538 */
     return 0;

@@ -267,7 +267,9 @@ int gecm_create(gecm_ctx **out, int device, const char *n_str, int digitbits)
     mpl_mulmod(&t, &c->rint_mod_n, &c->rint_mod_n, &c->N);
     mpl_mulmod(&t, &t, &c->rint_mod_n, &c->N);
     mpl_to_limbs32(c->r3_28, 1, nl, LIMB_BITS, &t);
-    gecm_dev_set_s2const(c->dev, c->r3_28, (uint32_t)(2 * c->nbits + 2));
+    /* batches of 28 division steps after which the device inversion has converged for a modulus of nbits bits:
+     * the bound of the "half-delta" variant, floor((45907 bits + 26313) / 19929), +1, rounded up to whole batches */
+    gecm_dev_set_s2const(c->dev, c->r3_28, (uint32_t)((((45907ull * (unsigned)c->nbits + 26313ull) / 19929ull + 1) + 27) / 28));
     row_setup(c);
     ff_setup(c);
     *out = c;
@@ -1000,6 +1002,25 @@ int gecm_stage2_pair(gecm_ctx *c, uint32_t steps, const uint32_t *pm_v, const ui
     c->s2_amin_last = t.amin_last;
     c->have_acc = 0;
     c->scan_valid[1] = 0;
+    return GECM_OK;
+}
+
+/* The pair map of [B1, B2) depends on nothing the device computes: a caller can have it made while stage 1 runs
+ * (gecm_stage1 returns after the launch).  Kept in the context; gecm_stage2 with the same (B2, D, U) finds it. */
+int gecm_stage2_prepare(gecm_ctx *c, uint64_t B2, uint32_t D, uint32_t U)
+{
+    const uint64_t PRIME_RANGE = 100000000ull;
+    if (!c || c->B1 == 0 || B2 <= c->B1) { set_err("gecm_stage2_prepare: call gecm_stage1 first; B2 > B1"); return GECM_ERR_ARG; }
+    if (!D) D = gecm_s2_default_D(c->B1);
+    if (!U) U = GECM_S2_DEFAULT_U;
+    if (B2 - c->B1 > PRIME_RANGE) return GECM_OK;                        /* several ranges: made range by range later */
+    if (c->pm_valid && c->pm_lo == c->B1 && c->pm_hi == B2 && c->pm_D == D && c->pm_U == U) return GECM_OK;
+    gecm_pairs pm;
+    int rc = gecm_pair_primes(&pm, c->B1, B2, D, U);
+    if (rc) return rc;
+    if (c->pm_valid) gecm_pairmap_release(&c->pm);
+    c->pm = pm;
+    c->pm_valid = 1; c->pm_lo = c->B1; c->pm_hi = B2; c->pm_D = D; c->pm_U = U;
     return GECM_OK;
 }
 

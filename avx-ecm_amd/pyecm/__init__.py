@@ -88,13 +88,14 @@ _sig("gecm_pairmap_release", None, ctypes.POINTER(Pairs))
 _sig("gecm_stage2_pair", c_int, c_void_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32),
      ctypes.POINTER(ctypes.c_uint32), ctypes.c_uint32)
 _sig("gecm_stage2", c_int, c_void_p, c_u64, ctypes.c_uint32, ctypes.c_uint32)
+_sig("gecm_stage2_prepare", c_int, c_void_p, c_u64, ctypes.c_uint32, ctypes.c_uint32)
 _sig("gecm_get_stage2_stats", c_int, c_void_p, ctypes.POINTER(Stage2Stats))
 _sig("gecm_download_acc", c_int, c_void_p, c_void_p)
 _sig("gecm_stage2_factor", c_int, c_void_p, c_size_t, c_char_p, c_size_t, ctypes.POINTER(c_int))
 _sig("gecm_scan_factors", c_int, c_void_p, c_int, ctypes.POINTER(c_size_t))
 _sig("gecm_curve_flag", c_int, c_void_p, c_int, c_size_t)
 EXPORTS += ["gecm_scan_factors", "gecm_curve_flag", "gecm_prepare_input", "gecm_sizeinbase10"]
-EXPORTS += ["gecm_stage2_init", "gecm_pair_primes", "gecm_pairmap_release", "gecm_stage2_pair", "gecm_stage2",
+EXPORTS += ["gecm_stage2_init", "gecm_pair_primes", "gecm_pairmap_release", "gecm_stage2_pair", "gecm_stage2", "gecm_stage2_prepare",
             "gecm_get_stage2_stats", "gecm_download_acc", "gecm_stage2_factor"]
 
 
@@ -276,6 +277,10 @@ class Engine:
     # ---- stage 2 ----
     def stage2(self, b2, D=0, U=0):
         _chk(lib.gecm_stage2(self._h, b2, D, U), "gecm_stage2")
+
+    def stage2_prepare(self, b2, D=0, U=0):
+        """host-side pair map for a later stage2(b2, D, U); callable while an asynchronous stage 1 runs"""
+        _chk(lib.gecm_stage2_prepare(self._h, b2, D, U), "gecm_stage2_prepare")
 
     def stage2_init(self, D=0, U=0, sync=True):
         _chk(lib.gecm_stage2_init(self._h, D, U), "gecm_stage2_init")

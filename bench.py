@@ -283,7 +283,12 @@ def main():
     found_log = []
 
     def step():
-        eng.stage1(a.b1, sync=True)
+        if a.b2 > a.b1 and not a.no_engine:
+            eng.stage1(a.b1, sync=False)
+            eng.stage2_prepare(a.b2)         # the pair map of [B1, B2), on the host while the device runs stage 1
+            eng.sync()
+        else:
+            eng.stage1(a.b1, sync=True)
         kernel_ms.append(eng.last_kernel_ms())
         # factor scan of the whole batch on the device (check_factor, ecm.c:2542-2557), then the ONE
         # collective of the path: max-reduce of the found record (lowest global curve with a factor);

@@ -206,6 +206,10 @@ int gecm_stage2_pair(gecm_ctx *ctx, uint32_t steps, const uint32_t *pairmap_v, c
 /* Convenience: the whole stage-2 sequence of vececm (ecm.c:1401-1476) for primes in [B1, B2):
  * init, then pair + stage2_pair per range of 1e8.  Synchronous.                                  */
 int gecm_stage2(gecm_ctx *ctx, uint64_t B2, uint32_t D, uint32_t U);
+/* Optional: make (and keep) the pair map gecm_stage2(ctx, B2, D, U) will need, e.g. between gecm_stage1 and
+ * gecm_sync, while the device runs stage 1 (the reference computes it between the stages, on the main thread:
+ * ecm.c:1441-1443).  Also kept after a gecm_stage2 call, so a run of many batches computes it once. */
+int gecm_stage2_prepare(gecm_ctx *ctx, uint64_t B2, uint32_t D, uint32_t U);
 
 typedef struct {
     uint64_t ptadds, numinv, paired;   /* the reference's counters, ecm.c:1482-1483 (numinv as the
