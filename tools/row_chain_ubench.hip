@@ -44,6 +44,28 @@ __global__ void __launch_bounds__(64, 2) k(uint32_t *out, uint32_t iters, uint32
             BODY8(asm volatile("v_mad_i64_i32 v[40:41], vcc, v42, v43, v[40:41]\n\tv_mov_b32_dpp v44, v40 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
                                "v_mad_u64_u32 v[40:41], vcc, v44, v43, v[40:41]\n\tv_mov_b32_dpp v46, v40 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
                                "v_mad_i64_i32 v[40:41], vcc, v41, 16, v[46:47]" : : : CLOB);)
+        } else if (KIND == 14) {  // independent DPP moves (throughput)
+            BODY8(asm volatile("v_mov_b32_dpp v44, v42 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp v46, v43 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : : : CLOB);)
+        } else if (KIND == 15) {  // independent plain moves (throughput)
+            BODY8(asm volatile("v_mov_b32 v44, v42\n\tv_mov_b32 v46, v43" : : : CLOB);)
+        } else if (KIND == 16) {  // independent ds_swizzle (throughput)
+            BODY8(asm volatile("ds_swizzle_b32 v44, v42 offset:swizzle(BROADCAST,16,3)\n\tds_swizzle_b32 v46, v43 offset:swizzle(SWAP,16)\n\ts_waitcnt lgkmcnt(0)" : : : CLOB);)
+        } else if (KIND == 17) {  // mad + independent dpp (mix, no dependence)
+            BODY8(asm volatile("v_mad_u64_u32 v[40:41], vcc, v42, v43, v[40:41]\n\tv_mov_b32_dpp v44, v43 row_newbcast:3 row_mask:0xf bank_mask:0xf" : : : CLOB);)
+        } else if (KIND == 18) {  // mad + independent v_mov
+            BODY8(asm volatile("v_mad_u64_u32 v[40:41], vcc, v42, v43, v[40:41]\n\tv_mov_b32 v44, v43" : : : CLOB);)
+        } else if (KIND == 19) {  // VALU throughput of the row's mix: 3 mads + 3 dpp, independent
+            BODY8(asm volatile("v_mad_u64_u32 v[40:41], vcc, v42, v43, v[40:41]\n\tv_mov_b32_dpp v44, v43 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+                               "v_mad_u64_u32 v[48:49], vcc, v42, v43, v[48:49]\n\tv_mov_b32_dpp v46, v43 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+                               "v_mad_u64_u32 v[50:51], vcc, v42, v43, v[50:51]\n\tv_mov_b32_dpp v47, v43 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : : : CLOB, "v48", "v49", "v50", "v51");)
+        } else if (KIND == 20) {  // the same with one dpp replaced by a ds_swizzle (waited for one body later)
+            BODY8(asm volatile("s_waitcnt lgkmcnt(0)\n\tv_mad_u64_u32 v[40:41], vcc, v42, v43, v[40:41]\n\tds_swizzle_b32 v44, v43 offset:swizzle(BROADCAST,16,3)\n\t"
+                               "v_mad_u64_u32 v[48:49], vcc, v42, v43, v[48:49]\n\tv_mov_b32_dpp v46, v43 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+                               "v_mad_u64_u32 v[50:51], vcc, v42, v43, v[50:51]\n\tv_mov_b32_dpp v47, v43 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : : : CLOB, "v48", "v49", "v50", "v51");)
+        } else if (KIND == 21) {  // 3 mads + 2 dpp only
+            BODY8(asm volatile("v_mad_u64_u32 v[40:41], vcc, v42, v43, v[40:41]\n\t"
+                               "v_mad_u64_u32 v[48:49], vcc, v42, v43, v[48:49]\n\tv_mov_b32_dpp v46, v43 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+                               "v_mad_u64_u32 v[50:51], vcc, v42, v43, v[50:51]\n\tv_mov_b32_dpp v47, v43 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : : : CLOB, "v48", "v49", "v50", "v51");)
         } else if (KIND == 12) {  // mul_lo chain (single pass multiplier?)
             BODY8(asm volatile("v_mul_lo_u32 v42, v42, v43" : : : CLOB);)
         } else if (KIND == 13) {  // mad_u32_u24 chain
@@ -92,6 +114,14 @@ int main()
     run<10>("mad + mov + permlane16_swap", 3);
     run<6>("row step (3 mad, 2 dpp)", 5);
     run<11>("row step without s_nop (timing only)", 5);
+    run<19>("3 mads + 3 dpp, independent", 6);
+    run<20>("3 mads + 2 dpp + 1 ds_swizzle, independent", 6);
+    run<21>("3 mads + 2 dpp, independent", 5);
+    run<14>("2 independent dpp moves", 2);
+    run<15>("2 independent plain moves", 2);
+    run<16>("2 independent ds_swizzle + waitcnt", 2);
+    run<17>("mad + independent dpp move", 2);
+    run<18>("mad + independent plain move", 2);
     run<12>("v_mul_lo_u32", 1);
     run<13>("v_mad_u32_u24", 1);
     return 0;
