@@ -220,8 +220,9 @@ def main():
     ap.add_argument("--lanes", type=int, default=0, help="lanes per curve in stage 1: 0 = library's choice, 1, 2, 8, 32")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; "
                     "gloo only to rehearse the multi-rank control flow)")
-    ap.add_argument("--b2", type=int, default=0, help="also time one stage-2 pass to this B2 on every rank "
-                    "(BASELINE configs[3]: 100000000); reported separately as \"stage2\"")
+    ap.add_argument("--b2", type=int, default=100000000, help="after the timed stage-1 steps, one stage-2 pass to this B2 on "
+                    "every rank's resident batch (BASELINE configs[3]: B2 = 1e8), reported separately as \"stage2\"; "
+                    "0 = none.  Not part of the metric, outside the timed region")
     ap.add_argument("--no-engine", action="store_true", help="rehearsal without a GPU: launcher + collectives only")
     a = ap.parse_args()
     t_begin = time.perf_counter()
@@ -282,11 +283,16 @@ def main():
     kernel_ms = []
     found_log = []
 
+    prepared = []
+
     def step():
-        if a.b2 > a.b1 and not a.no_engine:
+        if a.b2 > a.b1 and not a.no_engine and not prepared:
+            # probe step only: the pair map of [B1, B2) is made on the host while the device runs stage 1
+            # (gecm_stage2_prepare; kept in the context for the stage-2 pass after the timed region)
             eng.stage1(a.b1, sync=False)
-            eng.stage2_prepare(a.b2)         # the pair map of [B1, B2), on the host while the device runs stage 1
+            eng.stage2_prepare(a.b2)
             eng.sync()
+            prepared.append(True)
         else:
             eng.stage1(a.b1, sync=True)
         kernel_ms.append(eng.last_kernel_ms())
@@ -335,7 +341,10 @@ def main():
         s2 = eng.stage2_stats()
         stage2 = {"B2": a.b2, "seconds": t2, "curves_per_s": total / t2, "D": s2.D, "U": s2.U,
                   "ptadds": s2.ptadds, "inversions": s2.numinv, "pair_muls": s2.paired,
-                  "curves_with_factor_rank0": nf2}
+                  "curves_with_factor_rank0": nf2,
+                  "stage1_plus_stage2_curves_per_s": total / (dt / steps + t2),
+                  "note": "BASELINE configs[3] per GPU: %d curves, stage 1 to B1=%d then stage 2 to B2=%d on the resident "
+                          "batch; not part of the metric" % (a.curves, a.b1, a.b2)}
 
     line = None
     if rank == 0:
