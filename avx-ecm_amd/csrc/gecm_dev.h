@@ -39,9 +39,10 @@ int gecm_dev_set_tape(gecm_dev *d, const uint8_t *tape, size_t len);
  * too small to fill the chip), 0 = let the device layer choose from the batch size and CU count */
 int gecm_dev_stage1(gecm_dev *d, int lanes_per_curve);
 int gecm_dev_auto_lanes(gecm_dev *d);
-/* constants of the 32-lanes-per-curve kernel (csrc/gecm_row.hpp): nq limbs per lane, GECM_ROW_KINDS x
+/* constants of the 32-lanes-per-curve kernel (csrc/gecm_row.hpp): nq limbs per lane, rows per multiply
+ * (gecm_row_shape), GECM_ROW_KINDS x
  * GECM_ROW_WORDS words (N' = m*N = -1 mod 2^28; N; entry factor; R mod N; K' of N), limb j at word j */
-int gecm_dev_set_rowconst(gecm_dev *d, int nq, const uint32_t *words);
+int gecm_dev_set_rowconst(gecm_dev *d, int nq, int rows, const uint32_t *words);
 /* F-form (modulus 2^k - 1, csrc/gecm_field.hpp): number of top limbs the kernel for `nl` limbs reads from
  * the modulus (all limbs below must be 2^28 - 1), and the switch that makes gecm_dev_stage1 use it. */
 int gecm_dev_fform_generic_limbs(int nl);

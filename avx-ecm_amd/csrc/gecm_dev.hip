@@ -57,7 +57,7 @@ struct gecm_dev {
     bool timed = false;
     uint32_t *dModQ = nullptr;   // N and K' limbs padded to 40 each, for the eight-lane kernel
     uint32_t *dRowC = nullptr;   // constants of the 32-lane kernel (gecm_dev_set_rowconst), GECM_ROW_KINDS x GECM_ROW_WORDS
-    int row_nq = 0;              // limbs per lane there; 0 = not available
+    int row_nq = 0, row_rows = 0; // limbs per lane and rows of a multiply there; 0 = not available
     int fform = 0;        // +1 / -1 / 2: modulus is 2^k - 1 / 2^k + 1 / 2^k - c and stage 1 uses the special multiply (gecm_dev_set_fform)
     int cus = 0;          // compute units of the device (4 SIMDs each)
     int last_lanes = 0;   // lanes per curve the last stage-1 launch used
@@ -124,16 +124,17 @@ extern "C" int gecm_dev_open(gecm_dev **out, int device, int nl, const uint32_t 
     return 0;
 }
 
-extern "C" int gecm_dev_set_rowconst(gecm_dev *d, int nq, const uint32_t *words)
+extern "C" int gecm_dev_set_rowconst(gecm_dev *d, int nq, int rows, const uint32_t *words)
 {
     HIPCHK(hipSetDevice(d->device));
-    if (nq < 1 || nq > GECM_ROW_MAXNQ || 16 * nq > GECM_ROW_WORDS) {
+    if (nq < 1 || nq > GECM_ROW_MAXNQ || 16 * nq > GECM_ROW_WORDS || rows < 1 || rows > 16 * nq || rows % nq) {
         g_err = "gecm_dev_set_rowconst: limbs per lane out of range";
         return -2;
     }
     if (!d->dRowC) HIPCHK(hipMalloc(&d->dRowC, GECM_ROW_KINDS * GECM_ROW_WORDS * sizeof(uint32_t)));
     HIPCHK(hipMemcpy(d->dRowC, words, GECM_ROW_KINDS * GECM_ROW_WORDS * sizeof(uint32_t), hipMemcpyHostToDevice));
     d->row_nq = nq;
+    d->row_rows = rows;
     return 0;
 }
 
@@ -331,7 +332,7 @@ extern "C" int gecm_dev_stage1(gecm_dev *d, int lanes_per_curve)
 #define X(n)                                                                                     \
     case n:                                                                                      \
         if (lanes_per_curve == 32) {                                                             \
-            if (gecm_launch_stage1_row(d->stream, d->row_nq, d->dTape, (uint32_t)d->tape_len,    \
+            if (gecm_launch_stage1_row(d->stream, d->row_nq, d->row_rows, d->dTape, (uint32_t)d->tape_len,    \
                                        d->dX, d->dZ, d->dS, d->stride, (uint32_t)d->nl,          \
                                        d->dRowC, d->rho,                                 \
                                        row_a_lds(d))) {                                      \

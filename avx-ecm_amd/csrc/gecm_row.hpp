@@ -93,11 +93,12 @@ __device__ __forceinline__ int64_t smad16_smad(int32_t x, int64_t add, int32_t y
     return r;
 }
 
-// r = a*b/R' mod (modulus of m), R' = 2^(448*NQ).  Operand limbs |.| < 2^29; result limbs in [-2^27-4, 2^27+4]
+// r = a*b/R' mod (modulus of m), R' = 2^(28*ROWS): ROWS = the limbs in use (a multiple of NQ, at most 16*NQ; limbs
+// from ROWS up are zero in every operand and in the modulus, so their rows would add nothing).  Operand limbs |.| < 2^29; result limbs in [-2^27-4, 2^27+4]
 // (top limb: whatever the value needs), |result| < |a||b|/R' + modulus.
 // ALDS: the limbs of a are broadcast through the LDS crossbar (ds_swizzle: no VALU issue slot, best from 3 wavefronts
 // per SIMD up) instead of DPP row_newbcast (which sits in a wait state the digit broadcast needs anyway: best at 2).
-template <int NQ, bool RHO1, bool ALDS>
+template <int NQ, int ROWS, bool RHO1, bool ALDS>
 __device__ __forceinline__ void fer_mul(FeR<NQ> &r, const FeR<NQ> &a, const FeR<NQ> &b, const RowMod<NQ> &m)
 {
     int32_t a4[NQ], b4[NQ];
@@ -115,7 +116,7 @@ __device__ __forceinline__ void fer_mul(FeR<NQ> &r, const FeR<NQ> &a, const FeR<
     //   * rows ND .. get theirs by ds_swizzle through the LDS crossbar (no VALU issue slot, but ~70 cycles), all
     //     requested in the slots of the first rows.
     // ALDS (3 or more wavefronts per SIMD hide the start-up latency): every limb by ds_swizzle, requested up front.
-    constexpr int ROWS = 16 * NQ;
+    static_assert(ROWS % NQ == 0 && ROWS <= 16 * NQ, "whole lanes, at most 16 of them");
     constexpr int ND = ALDS ? 0 : (GECM_ROW_DPP_ROWS < ROWS ? GECM_ROW_DPP_ROWS : ROWS);
     int32_t Ab[ROWS];
     auto request = [&](auto jc) {
@@ -232,26 +233,26 @@ __device__ __forceinline__ void row_forms(PtR<NQ> &p, const RowSign &g)
 }
 
 // T = A + B with difference C (vec_add, ecm.c:407-443): fB = B.ds, fA = A.sd, c = C.oth
-template <int NQ, bool ALDS>
+template <int NQ, int ROWS, bool ALDS>
 __device__ __forceinline__ void row_add(PtR<NQ> &T, const FeR<NQ> &fB, const FeR<NQ> &fA, const FeR<NQ> &c, bool isZ,
                                         const RowSign &g, const RowMod<NQ> &m)
 {
     FeR<NQ> w, t, e;
-    fer_mul<NQ, true, ALDS>(w, fB, fA, m);            // X: U      Z: V
+    fer_mul<NQ, ROWS, true, ALDS>(w, fB, fA, m);            // X: U      Z: V
     fer_other<NQ>(t, w);
     fer_sum_diff<NQ>(e, t, w, g);                     // X: V + U  Z: U - V
-    fer_mul<NQ, true, ALDS>(e, e, e, m);
-    fer_mul<NQ, true, ALDS>(T.own, e, c, m);
+    fer_mul<NQ, ROWS, true, ALDS>(e, e, e, m);
+    fer_mul<NQ, ROWS, true, ALDS>(T.own, e, c, m);
     row_forms<NQ>(T, g);
 }
 
 // D = 2A (vec_duplicate, ecm.c:445-457): fA = A.sd, s4 = (A+2)/4 of the curve
-template <int NQ, bool ALDS>
+template <int NQ, int ROWS, bool ALDS>
 __device__ __forceinline__ void row_dup(PtR<NQ> &D, const FeR<NQ> &fA, const FeR<NQ> &s4, bool isZ, const RowSign &g,
                                         const RowMod<NQ> &m)
 {
     FeR<NQ> q, t, w, p1, p2, r1;
-    fer_mul<NQ, true, ALDS>(q, fA, fA, m);            // X: U = (x+z)^2    Z: V = (x-z)^2
+    fer_mul<NQ, ROWS, true, ALDS>(q, fA, fA, m);            // X: U = (x+z)^2    Z: V = (x-z)^2
     fer_other<NQ>(t, q);                              // X: V              Z: U
 #pragma unroll
     for (int i = 0; i < NQ; i++) {
@@ -259,10 +260,10 @@ __device__ __forceinline__ void row_dup(PtR<NQ> &D, const FeR<NQ> &fA, const FeR
         p1.v[i] = isZ ? s4.v[i] : q.v[i];
         p2.v[i] = isZ ? w.v[i] : t.v[i];
     }
-    fer_mul<NQ, true, ALDS>(r1, p1, p2, m);           // X: U*V            Z: s*w
+    fer_mul<NQ, ROWS, true, ALDS>(r1, p1, p2, m);           // X: U*V            Z: s*w
 #pragma unroll
     for (int i = 0; i < NQ; i++) t.v[i] = r1.v[i] + q.v[i];     // Z: s*w + V
-    fer_mul<NQ, true, ALDS>(t, t, w, m);              // Z: (s*w + V)*w
+    fer_mul<NQ, ROWS, true, ALDS>(t, t, w, m);              // Z: (s*w + V)*w
 #pragma unroll
     for (int i = 0; i < NQ; i++) D.own.v[i] = isZ ? t.v[i] : r1.v[i];
     row_forms<NQ>(D, g);
@@ -280,7 +281,7 @@ __device__ __forceinline__ void fer_load(FeR<NQ> &r, const uint32_t *__restrict_
 }
 
 // run_tape_quad of gecm_quad.hpp on rows: A, B, C are this lane's limbs of its coordinate (and their forms).
-template <int NQ, bool ALDS>
+template <int NQ, int ROWS, bool ALDS>
 __device__ __forceinline__ void run_tape_row(const uint32_t *__restrict__ tape, uint32_t tape_len, PtR<NQ> &A,
                                              const FeR<NQ> &s4, bool isZ, const RowSign &g, const RowMod<NQ> &m)
 {
@@ -300,7 +301,7 @@ __device__ __forceinline__ void run_tape_row(const uint32_t *__restrict__ tape, 
                 B = t;
             }
             PtR<NQ> T;
-            row_add<NQ, ALDS>(T, B.ds, A.sd, C.oth, isZ, g, m);
+            row_add<NQ, ROWS, ALDS>(T, B.ds, A.sd, C.oth, isZ, g, m);
             C = B;
             B = T;
             pc++;
@@ -331,8 +332,8 @@ __device__ __forceinline__ void run_tape_row(const uint32_t *__restrict__ tape, 
             C = A;
         }
         PtR<NQ> T, D;
-        if (do_add) row_add<NQ, ALDS>(T, B.ds, A.sd, C.oth, isZ, g, m);
-        if (do_dup) row_dup<NQ, ALDS>(D, A.sd, s4, isZ, g, m);
+        if (do_add) row_add<NQ, ROWS, ALDS>(T, B.ds, A.sd, C.oth, isZ, g, m);
+        if (do_dup) row_dup<NQ, ROWS, ALDS>(D, A.sd, s4, isZ, g, m);
         if (op == GECM_OP_PRAC_END) {
             A = T;
         } else if (op == GECM_OP_PRAC_BEGIN) {
@@ -360,7 +361,7 @@ __device__ __forceinline__ void run_tape_row(const uint32_t *__restrict__ tape, 
 // (GECM_ROW_WORDS, GECM_ROW_KINDS: gecm_rowk.h)
 
 // The whole stage-1 kernel body for one lane.  nl = limbs per residue in the device buffers (R = 2^(28*nl)).
-template <int NQ, bool ALDS>
+template <int NQ, int ROWS, bool ALDS>
 __device__ __forceinline__ void stage1_row(const uint32_t *__restrict__ tape, uint32_t tape_len, uint32_t *__restrict__ X,
                                            uint32_t *__restrict__ Z, const uint32_t *__restrict__ S, size_t stride,
                                            uint32_t nl, const uint32_t *__restrict__ rc, uint32_t rho_n)
@@ -385,7 +386,7 @@ __device__ __forceinline__ void stage1_row(const uint32_t *__restrict__ tape, ui
     PtR<NQ> P;
     FeR<NQ> s4, t;
     fer_load<NQ>(t, mine, stride, cidx, l, nl);
-    fer_mul<NQ, true, ALDS>(P.own, t, cin, mp);             // x*R -> x*R' (mod N')
+    fer_mul<NQ, ROWS, true, ALDS>(P.own, t, cin, mp);             // x*R -> x*R' (mod N')
     RowSign g;
     g.mz = isZ ? 0xffffffffu : 0u;
     g.bz = isZ ? 1u : 0u;
@@ -393,9 +394,9 @@ __device__ __forceinline__ void stage1_row(const uint32_t *__restrict__ tape, ui
     g.bx = 1u - g.bz;
     row_forms<NQ>(P, g);
     fer_load<NQ>(t, S, stride, cidx, l, nl);
-    fer_mul<NQ, true, ALDS>(s4, t, cin, mp);
-    run_tape_row<NQ, ALDS>(tape, tape_len, P, s4, isZ, g, mp);
-    fer_mul<NQ, false, ALDS>(t, P.own, one, mn);                    // x*R' -> x*R (mod N), in (-N/16, 17N/16)
+    fer_mul<NQ, ROWS, true, ALDS>(s4, t, cin, mp);
+    run_tape_row<NQ, ROWS, ALDS>(tape, tape_len, P, s4, isZ, g, mp);
+    fer_mul<NQ, ROWS, false, ALDS>(t, P.own, one, mn);                    // x*R' -> x*R (mod N), in (-N/16, 17N/16)
     // + K' (a multiple of N with every limb >= 2^28 - 1): all limbs positive; then one carry-save pass
     uint32_t u[NQ];
 #pragma unroll

@@ -1,39 +1,38 @@
 // gecm_rowk.hip — the 32-lanes-per-curve stage-1 kernels (gecm_row.hpp).  One translation unit for all limb
-// counts: the kernel is templated on the limbs per lane (NQ = 1, 2, 3 cover 16, 32, 48 limbs of 28 bits), the
-// limb count of the device buffers is a run-time argument.
+// counts: the kernel is templated on the limbs per lane (NQ = 1, 2, 3 cover up to 16, 32, 48 limbs of 28 bits) and on
+// the rows of a multiply (ROWS = the limbs of N' = m*N rounded up to whole lanes); the limb count of the device
+// buffers is a run-time argument.
 #include "gecm_row.hpp"
 #include <hip/hip_runtime.h>
 
-template <int NQ, bool ALDS>
+template <int NQ, int ROWS, bool ALDS>
 __global__ void __launch_bounds__(64, 2)
 k_stage1_row(const uint32_t *__restrict__ tape, uint32_t tape_len, uint32_t *__restrict__ X, uint32_t *__restrict__ Z,
              const uint32_t *__restrict__ S, size_t stride, uint32_t nl, const uint32_t *__restrict__ rc, uint32_t rho_n)
 {
-    stage1_row<NQ, ALDS>(tape, tape_len, X, Z, S, stride, nl, rc, rho_n);
+    stage1_row<NQ, ROWS, ALDS>(tape, tape_len, X, Z, S, stride, nl, rc, rho_n);
 }
 
 /* rc = device array of GECM_ROW_KINDS x GECM_ROW_WORDS words (gecm_row.hpp).  Leaves lazy values (limbs < 2^28 + 4,
  * value < K + 2N) in X, Z: the caller runs k_canon afterwards.  a_lds: operand broadcasts through the LDS crossbar
- * (for launches of 3 or more wavefronts per SIMD).  Returns -1 if nq is not built. */
-extern "C" int gecm_launch_stage1_row(void *stream, int nq, const uint32_t *tape, uint32_t tape_len, uint32_t *X,
+ * (for launches of 3 or more wavefronts per SIMD).  (nq, rows) must be one of the built pairs — gecm_row_shape() of a
+ * built limb count; returns -1 otherwise. */
+extern "C" int gecm_launch_stage1_row(void *stream, int nq, int rows, const uint32_t *tape, uint32_t tape_len, uint32_t *X,
                                       uint32_t *Z, const uint32_t *S, size_t stride, uint32_t nl, const uint32_t *rc,
                                       uint32_t rho_n, int a_lds)
 {
     const dim3 grid((unsigned)(stride / 2)), block(64);
-#define GECM_ROW_LAUNCH(q)                                                                                                  \
-    case q:                                                                                                                 \
+#define GECM_ROW_LAUNCH(q, r)                                                                                               \
+    if (nq == q && rows == r) {                                                                                             \
         if (a_lds)                                                                                                          \
-            hipLaunchKernelGGL((k_stage1_row<q, true>), grid, block, 0, (hipStream_t)stream, tape, tape_len, X, Z, S,       \
+            hipLaunchKernelGGL((k_stage1_row<q, r, true>), grid, block, 0, (hipStream_t)stream, tape, tape_len, X, Z, S,    \
                                stride, nl, rc, rho_n);                                                                      \
         else                                                                                                                \
-            hipLaunchKernelGGL((k_stage1_row<q, false>), grid, block, 0, (hipStream_t)stream, tape, tape_len, X, Z, S,      \
+            hipLaunchKernelGGL((k_stage1_row<q, r, false>), grid, block, 0, (hipStream_t)stream, tape, tape_len, X, Z, S,   \
                                stride, nl, rc, rho_n);                                                                      \
-        return 0;
-    switch (nq) {
-        GECM_ROW_LAUNCH(1)
-        GECM_ROW_LAUNCH(2)
-        GECM_ROW_LAUNCH(3)
+        return 0;                                                                                                           \
     }
+    GECM_ROW_SHAPES(GECM_ROW_LAUNCH)
 #undef GECM_ROW_LAUNCH
     return -1;
 }

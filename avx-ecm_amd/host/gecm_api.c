@@ -172,15 +172,15 @@ static void ff_setup(gecm_ctx *c)
 }
 
 /* Constants of the 32-lanes-per-curve stage-1 kernel (csrc/gecm_row.hpp): it works modulo N' = m*N, the multiple
- * of N that is -1 modulo 2^28 (the Montgomery digit is then the low limb itself), on L = 16*nq limbs with
- * R' = 2^(28 L) >= 32 N'.  Entry factor R'^2/R mod N turns the buffers' x*R into x*R'; the exit multiply by R mod N
+ * of N that is -1 modulo 2^28 (the Montgomery digit is then the low limb itself), on L limbs (nl + 1 rounded up
+ * to whole lanes of nq limbs) with R' = 2^(28 L) >= 32 N'.  Entry factor R'^2/R mod N turns the buffers' x*R into x*R'; the exit multiply by R mod N
  * (modulo N itself) turns it back.  Not an error if it cannot be set up: the other layouts cover every N. */
 static void row_setup(gecm_ctx *c)
 {
     const int nl = c->nl;
-    const int nq = (nl + 1 + 15) / 16;               /* 28 (nl + 1) >= bits(N') + 5 */
+    int nq, L;                                        /* L = rows of a multiply = limbs in use: 28 (nl + 1) >= bits(N') + 5 */
+    gecm_row_shape(nl, &nq, &L);
     if (nq > GECM_ROW_MAXNQ) return;
-    const int L = 16 * nq;
     uint32_t w[GECM_ROW_KINDS * GECM_ROW_WORDS];
     memset(w, 0, sizeof w);
     mpl_t two28, inv, m, np, t;
@@ -196,7 +196,7 @@ static void row_setup(gecm_ctx *c)
     mpl_to_limbs32(w + 2 * GECM_ROW_WORDS, 1, nl, LIMB_BITS, &t);
     memcpy(w + 3 * GECM_ROW_WORDS, c->one28, (size_t)nl * sizeof(uint32_t));
     memcpy(w + 4 * GECM_ROW_WORDS, c->kp28, (size_t)nl * sizeof(uint32_t));
-    (void)gecm_dev_set_rowconst(c->dev, nq, w);
+    (void)gecm_dev_set_rowconst(c->dev, nq, L, w);
 }
 
 int gecm_create(gecm_ctx **out, int device, const char *n_str, int digitbits)

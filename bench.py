@@ -53,8 +53,9 @@ KERNEL_NAMES = {1: "k_stage1<%d>", 2: "k_stage1_pair<%d>", 8: "k_stage1_quad<%d>
 
 def kernel_name(lanes, dev_limbs):
     """the stage-1 kernel a launch with this layout runs, as rocprofv3 prints it"""
-    if lanes == 32:        # templated on limbs per lane (16 lanes per residue, one limb more than the buffers hold)
-        return "k_stage1_row<%d, false>" % ((dev_limbs + 1 + 15) // 16)
+    if lanes == 32:        # templated on limbs per lane and rows of a multiply (one limb more than the buffers hold)
+        nq = (dev_limbs + 1 + 15) // 16
+        return "k_stage1_row<%d, %d, false>" % (nq, nq * ((dev_limbs + nq) // nq))
     return KERNEL_NAMES.get(lanes, "k_stage1_l%d<%%d>" % lanes) % dev_limbs
 
 

@@ -21,7 +21,7 @@ __global__ void __launch_bounds__(64, 2) k_check(const int32_t *in, int32_t *out
         b.v[t] = in[(size_t)g * 32 * NQ + 16 * NQ + NQ * l + t];
     }
     m.rho = rho;
-    fer_mul<NQ, RHO1, false>(r, a, b, m);
+    fer_mul<NQ, 16 * NQ, RHO1, false>(r, a, b, m);
     for (int t = 0; t < NQ; t++) out[(size_t)g * 16 * NQ + NQ * l + t] = r.v[t];
 }
 
@@ -38,8 +38,8 @@ __global__ void __launch_bounds__(64, 2) k_chain(const int32_t *in, int32_t *out
     }
     m.rho = rho;
     for (uint32_t i = 0; i < iters; i++) {
-        fer_mul<NQ, RHO1, false>(a, a, b, m);
-        fer_mul<NQ, RHO1, false>(b, b, a, m);
+        fer_mul<NQ, 16 * NQ, RHO1, false>(a, a, b, m);
+        fer_mul<NQ, 16 * NQ, RHO1, false>(b, b, a, m);
     }
     for (int t = 0; t < NQ; t++) out[(size_t)(blockIdx.x * 64 + threadIdx.x) * NQ + t] = a.v[t] + b.v[t];
 }
