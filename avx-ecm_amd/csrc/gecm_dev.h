@@ -87,7 +87,6 @@ int gecm_dev_s2_download(gecm_dev *d, uint32_t *acc, uint32_t *fail);
 /* factor scan on the device: which = 0 -> stage-1 Z, 1 -> stage-2 accumulator.  flags[curve] = 1 iff
  * 1 < gcd(value, N) < N; g = the gcds ([limb][curve]); either output may be NULL. */
 int gecm_dev_gcd_scan(gecm_dev *d, int which, uint32_t *flags, uint32_t *g);
-size_t gecm_dev_s2_bytes(int nl, size_t ncurves, uint32_t npb, uint32_t G, uint32_t ring_size);
 
 #ifdef __cplusplus
 }

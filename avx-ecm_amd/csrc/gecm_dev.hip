@@ -445,13 +445,6 @@ extern "C" int gecm_dev_set_s2const(gecm_dev *d, const uint32_t *r3, uint32_t in
     return 0;
 }
 
-extern "C" size_t gecm_dev_s2_bytes(int nl, size_t ncurves, uint32_t npb, uint32_t G, uint32_t ring_size)
-{
-    size_t stride = (ncurves + 63) / 64 * 64;
-    size_t coord = (size_t)nl * stride * 4;
-    return coord * ((size_t)npb + 3 * GECM_S2_BLK + 2 + 1 + 32 /* acc slices, upper bound */ + 2 * ((size_t)G + 2) + (size_t)G + (size_t)ring_size);
-}
-
 /* Sub-sequences per curve for the stage-2 table build and giant steps: those are one dependent chain per curve, so a
  * batch of a few thousand curves (a few dozen wavefronts) is split into K interleaved chains per curve until there
  * are 2 wavefronts per SIMD (csrc/gecm_stage2.hpp, s2_init_k / giant_chunk_k).  1 for batches that fill the chip.
