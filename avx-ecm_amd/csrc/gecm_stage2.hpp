@@ -296,7 +296,7 @@ __device__ __forceinline__ void block_normalise(uint32_t *__restrict__ out, uint
 
 // P <- [c]P, binary ladder (next_pt_vec, ecm.c:886-976); c is wave-uniform.
 template <int NL>
-__device__ __forceinline__ void pt_ladder(Pt<NL> &P, uint64_t c, const Fe<NL> &s4, const ModK<NL> &m)
+__device__ __noinline__ void pt_ladder(Pt<NL> &P, uint64_t c, const Fe<NL> &s4, const ModK<NL> &m)
 {
     if (c == 1) return;
     Fe<NL> s1, d1, s2, d2;
