@@ -245,7 +245,9 @@ def main():
         ndev = max(1, pyecm.device_count())
         devno = local_rank % ndev
     on_gpu = not a.no_engine and (world == 1 or a.backend == "nccl")
-    if world > 1:
+    if "WORLD_SIZE" in os.environ:
+        # launched as a rank (torch.distributed.run): the process group is made even for a world of one, so that
+        # a one-GPU box exercises the same RCCL path (init, barrier, all-reduce on device tensors) as N ranks
         import torch.distributed as dist
         if a.backend == "nccl":
             torch.cuda.set_device(devno)

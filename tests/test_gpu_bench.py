@@ -1,0 +1,40 @@
+"""bench.py on the GPU box: as a plain process and as a rank under torch.distributed.run (a world of one still makes
+the RCCL process group, so init, barrier and the found-record all-reduce on device tensors run on hardware)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+ARGS = ["--gpus", "1", "--steps", "2", "--warmup", "1", "--b1", "20000", "--b2", "400000", "--curves", "256", "--no-extras",
+        "--no-cpu-baseline"]
+
+
+def _line(cmd):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    return lines[0]
+
+
+def test_bench_line_has_the_contract_s_fields():
+    d = _line([sys.executable, "bench.py"] + ARGS)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["unit"] == "curves/s" and d["value"] > 0
+    assert d["config"]["curves_per_gpu"] == 256 and d["config"]["lanes_per_curve"] == 32
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms_avg")) <= set(d["roofline"])
+    assert d["stage2"]["B2"] == 400000 and d["stage2"]["seconds"] > 0
+
+
+def test_bench_as_a_rank_under_torch_distributed_run():
+    d = _line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+               "--master-port", "29541", "bench.py"] + ARGS)
+    assert d["n_gpus"] == 1 and "RCCL" in d["config"]["parallelism"] and d["value"] > 0
