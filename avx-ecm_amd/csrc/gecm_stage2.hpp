@@ -66,6 +66,63 @@ __device__ __forceinline__ void tb_store(uint32_t *__restrict__ base, uint32_t n
     for (int i = 0; i < NL; i++) *(uint32_t *)(p + i * 256 + boff) = r.v[i];
 }
 
+// Table rows whose arrival the pair walk waits for by hand.  The compiler's own s_waitcnt placement drains the whole
+// queue (vmcnt(0)) at the top of every pair — the row load that is conditional on the giant step changing makes its
+// count unknown — so the rows requested for the NEXT pairs were waited for too and the lookahead hid nothing.  These
+// loads are inline asm (the compiler does not count them); tb_wait() waits until at most `newer` x NL loads issued
+// after the row are still out (loads complete in order; compiler-issued loads in between only make the wait longer)
+// and ties the row's registers to that point.  vmcnt holds 6 bits: above 63 the wait is simply for more.
+// No "memory" clobber on these statements: the tables are read-only in the kernels that use them, and a clobber would
+// stop the compiler from fetching the wave-uniform tape words with scalar loads (its vector loads come with vmcnt(0)).
+#ifndef GECM_S2_ASYNC_MAXNL
+#define GECM_S2_ASYNC_MAXNL 16
+#endif
+template <int NL>
+__device__ __forceinline__ void tb_load_async(Fe<NL> &r, const uint32_t *__restrict__ base, uint32_t nent, uint32_t idx, size_t e)
+{
+    // Only while every row in flight stays in registers: a row the compiler moves to scratch would be moved before it
+    // has arrived.  Larger residues keep compiler-visible loads.
+    if constexpr (NL > GECM_S2_ASYNC_MAXNL) {
+        tb_load(r, base, nent, idx, e);
+        return;
+    }
+    // the row address is wave-uniform; say so in a way that survives the table pointer arriving in vector registers
+    const uint64_t pv = (uint64_t)tb_ptr<NL>(base, nent, idx, e);
+    const uint32_t phi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(pv >> 32));
+    const uint32_t plo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)pv);      // the builtin returns int: no sign extension
+    const uint32_t *p = (const uint32_t *)(((uint64_t)phi << 32) | (uint64_t)plo);
+    const uint32_t boff = (idx & 63u) * 4u;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        const uint32_t *pc = p + (i / 16) * 1024;              // the immediate offset reaches 4095 bytes
+        asm volatile("global_load_dword %0, %1, %2 offset:%3" : "=v"(r.v[i]) : "v"(boff), "s"(pc), "n"((i % 16) * 256));
+    }
+}
+template <int NL, int I0, int N>
+__device__ __forceinline__ void tb_tie(Fe<NL> &r)
+{
+    if constexpr (NL > GECM_S2_ASYNC_MAXNL) return;
+    if constexpr (N >= 8)
+        asm volatile("" : "+v"(r.v[I0]), "+v"(r.v[I0 + 1]), "+v"(r.v[I0 + 2]), "+v"(r.v[I0 + 3]), "+v"(r.v[I0 + 4]), "+v"(r.v[I0 + 5]),
+                     "+v"(r.v[I0 + 6]), "+v"(r.v[I0 + 7]));
+    else if constexpr (N >= 1)
+        asm volatile("" : "+v"(r.v[I0]));
+    if constexpr (N >= 8) tb_tie<NL, I0 + 8, N - 8>(r);
+    else if constexpr (N >= 2) tb_tie<NL, I0 + 1, N - 1>(r);
+}
+template <int NL, int NEWER>
+__device__ __forceinline__ void tb_wait_cnt()
+{
+    constexpr int cnt = NL * NEWER > 63 ? 63 : NL * NEWER;
+    if constexpr (NL <= GECM_S2_ASYNC_MAXNL) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(cnt));
+}
+template <int NL, int NEWER>
+__device__ __forceinline__ void tb_wait(Fe<NL> &r)
+{
+    tb_wait_cnt<NL, NEWER>();
+    tb_tie<NL, 0, NL>(r);
+}
+
 // ---- exact helpers on fully normalised values ----------------------------------------------
 // r = a - b, returns borrow (1 if a < b); limbs normalised in and out (result mod 2^(28 NL))
 template <int NL>
@@ -294,15 +351,48 @@ __device__ __forceinline__ void block_normalise(uint32_t *__restrict__ out, uint
     tb_store(out, out_nent, idx, where(0), x);
 }
 
-// P <- [c]P, binary ladder (next_pt_vec, ecm.c:886-976); c is wave-uniform.
+// The ladders of the stage-2 set-up run a handful of times per launch, but there are eight call sites of them and each
+// holds eleven residue multiplies: inlined, the 37-limb translation unit took over five minutes to compile.  From
+// GECM_LADDER_OL_NL limbs on the ladder's multiplies are calls to one out-of-line multiply and one square (operands
+// through memory: ~3*NL words against NL^2 multiply-adds).  (The whole ladder out of line was tried first: with this
+// ROCm it gave wrong points, and from 28 limbs on stopped the code generator inside k_s2_init_k.)
+#ifndef GECM_LADDER_OL_NL
+#define GECM_LADDER_OL_NL 20
+#endif
 template <int NL>
-__device__ __noinline__ void pt_ladder(Pt<NL> &P, uint64_t c, const Fe<NL> &s4, const ModK<NL> &m)
+struct ModKOut {
+    const ModK<NL> &m;
+};
+template <int NL>
+__device__ __noinline__ void fe_mul_ol(Fe<NL> &r, const Fe<NL> &a, const Fe<NL> &b, const ModK<NL> &m)
+{
+    Fe<NL> x = a, y = b, t;
+    fe_mul(t, x, y, m);
+    r = t;
+}
+template <int NL>
+__device__ __noinline__ void fe_sqr_ol(Fe<NL> &r, const Fe<NL> &a, const ModK<NL> &m)
+{
+    Fe<NL> x = a, t;
+    fe_sqr(t, x, m);
+    r = t;
+}
+template <int NL>
+__device__ __forceinline__ void fe_mul(Fe<NL> &r, const Fe<NL> &a, const Fe<NL> &b, const ModKOut<NL> &o) { fe_mul_ol(r, a, b, o.m); }
+template <int NL>
+__device__ __forceinline__ void fe_sqr(Fe<NL> &r, const Fe<NL> &a, const ModKOut<NL> &o) { fe_sqr_ol(r, a, o.m); }
+template <int NL>
+__device__ __forceinline__ void fe_sub(Fe<NL> &r, const Fe<NL> &a, const Fe<NL> &b, const ModKOut<NL> &o) { fe_sub(r, a, b, o.m); }
+
+// P <- [c]P, binary ladder (next_pt_vec, ecm.c:886-976); c is wave-uniform.  MM = ModK<NL> or ModKOut<NL>.
+template <int NL, class MM>
+__device__ __forceinline__ void pt_ladder_body(Pt<NL> &P, uint64_t c, const Fe<NL> &s4, const ModK<NL> &m, const MM &mm_)
 {
     if (c == 1) return;
     Fe<NL> s1, d1, s2, d2;
     Pt<NL> p1 = P, p2;
     pt_sumdiff(s1, d1, P, m);
-    pt_dup(p2, s1, d1, s4, m);
+    pt_dup(p2, s1, d1, s4, mm_);
     if (c == 2) { P = p2; return; }
     int top = 63 - __builtin_clzll(c);
     for (int bit = top - 1; bit >= 0; bit--) {
@@ -314,16 +404,22 @@ __device__ __noinline__ void pt_ladder(Pt<NL> &P, uint64_t c, const Fe<NL> &s4, 
         pt_sumdiff(s2, d2, p2, m);
         pt_sumdiff(s1, d1, p1, m);
         Fe<NL> pp, mm;
-        pt_add_uv(pp, mm, s1, d1, s2, d2, m);
+        pt_add_uv(pp, mm, s1, d1, s2, d2, mm_);
         Pt<NL> T, D;
-        fe_mul(T.X, pp, P.Z, m);
-        fe_mul(T.Z, mm, P.X, m);
-        pt_dup(D, s1, d1, s4, m);
+        fe_mul(T.X, pp, P.Z, mm_);
+        fe_mul(T.Z, mm, P.X, mm_);
+        pt_dup(D, s1, d1, s4, mm_);
         p2 = T;
         p1 = D;
         if (b) { Pt<NL> t = p1; p1 = p2; p2 = t; }
     }
     P = p1;
+}
+template <int NL>
+__device__ __forceinline__ void pt_ladder(Pt<NL> &P, uint64_t c, const Fe<NL> &s4, const ModK<NL> &m)
+{
+    if constexpr (NL >= GECM_LADDER_OL_NL) pt_ladder_body(P, c, s4, m, ModKOut<NL>{m});
+    else pt_ladder_body(P, c, s4, m, m);
 }
 
 struct S2InitArgs {
@@ -669,55 +765,67 @@ __device__ __forceinline__ void s2_pairs(const S2PairArgs &a, uint32_t first, ui
     Fe<NL> acc;
     fe_load(acc, accbuf, stride, idx);
     // Lookahead: the baby-step rows of the next DEPTH pairs are in flight while the current pair is
-    // multiplied, so HBM latency (2-3 us under load) hides behind the arithmetic.  The host sorts the
+    // multiplied, so HBM latency (2-3 us under load) hides behind the arithmetic (tb_load_async / tb_wait_cnt).  The host sorts the
     // pairs of a segment by giant step (the product is order-independent), so the ring row is
     // re-read only when the giant step changes: per pair one 4*NL-byte row of the 461-KB-per-curve
     // baby-step table comes from HBM instead of two rows (the walk is HBM-bound otherwise:
     // 2*60 B x 131,072 curves x 3.0 M pairs = 47 TB at B2 = 1e8).
     const uint32_t *st = a.steps + 2 * (size_t)first;
     constexpr int DEPTH = GECM_S2_DEPTH;              // table rows in flight per lane
+    static_assert(64 % DEPTH == 0, "a block of 64 tape entries is walked in groups of DEPTH");
     Fe<NL> x, yq[DEPTH];
-    // tape words are fetched one group ahead too (scalar loads): cs = giant-step slots of the current
-    // group of DEPTH pairs, rb = table indices of the group after it (the rows to request next)
-    auto word = [&](uint32_t j, uint32_t w) -> uint32_t {
-        const uint32_t jj = j < count ? j : count - 1;       // clamp: never read past the segment
-        return __builtin_amdgcn_readfirstlane(st[2 * jj + w]);
+    // The tape is read 64 entries at a time, one entry per lane (coalesced), and handed out with v_readlane: `cs` =
+    // giant-step slots of this block's pairs, `ca` = table indices of the pairs DEPTH ahead of them (the rows to
+    // request next).  The words of the next block (ns, na) are requested at the top of a block and first touched at the
+    // top of the next one, behind an empty asm, so that the compiler's wait for them — a vmcnt(0): it does not count
+    // the asm loads — sits there, once per 64 pairs, and nowhere inside the walk.  Entries past the segment repeat
+    // its last one.
+    const uint32_t lane = idx & 63u;
+    auto ld = [&](uint32_t j, uint32_t w) -> uint32_t {
+        j = j < count ? j : count - 1;
+        return st[2 * (size_t)j + w];
     };
-    uint32_t cs[DEPTH], rb[DEPTH], ns[DEPTH], nr[DEPTH];
-#pragma unroll
-    for (int d = 0; d < DEPTH; d++) {
-        cs[d] = word((uint32_t)d, 0);
-        rb[d] = word((uint32_t)(d + DEPTH), 1);
-    }
-    uint32_t slot = cs[0];
-    tb_load(x, a.ring, a.ring_size, idx, slot);
+    auto rl = [](uint32_t v, uint32_t l) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); };
+    uint32_t ns = ld(lane, 0), na = ld(lane + DEPTH, 1), p0 = ld(lane, 1);
+    tb_tie<NL, 0, NL>(acc);                               // the accumulator has arrived before the first request
+    asm volatile("" : "+v"(ns), "+v"(na), "+v"(p0));
+    uint32_t slot = rl(ns, 0);
+    tb_load_async(x, a.ring, a.ring_size, idx, slot);
+    tb_wait<NL, 0>(x);
 #pragma unroll
     for (int d = 0; d < DEPTH; d++)
-        if ((uint32_t)d < count) tb_load(yq[d], a.PbX, a.npb, idx, word((uint32_t)d, 1));
-    for (uint32_t i = 0; i < count; i += DEPTH) {
+        if ((uint32_t)d < count) tb_load_async(yq[d], a.PbX, a.npb, idx, rl(p0, (uint32_t)d));
+    for (uint32_t b0 = 0; b0 < count; b0 += 64) {
+        uint32_t cs = ns, ca = na;
+        asm volatile("" : "+v"(cs), "+v"(ca));
+        ns = ld(b0 + 64 + lane, 0);
+        na = ld(b0 + 64 + lane + DEPTH, 1);
+        for (uint32_t jj = 0; jj < 64; jj += DEPTH) {
+            if (b0 + jj >= count) break;
 #pragma unroll
-        for (int d = 0; d < DEPTH; d++) {
-            ns[d] = word(i + DEPTH + (uint32_t)d, 0);
-            nr[d] = word(i + 2 * DEPTH + (uint32_t)d, 1);
-        }
-#pragma unroll
-        for (int d = 0; d < DEPTH; d++) {
-            const uint32_t j = i + (uint32_t)d;
-            if (j < count) {
-                if (cs[d] != slot) {                  // next giant step (pairs are sorted by it)
-                    slot = cs[d];
-                    tb_load(x, a.ring, a.ring_size, idx, slot);
+            for (int d = 0; d < DEPTH; d++) {
+                const uint32_t l = jj + (uint32_t)d;
+                const uint32_t j = b0 + l;
+                if (j < count) {
+                    const uint32_t sl = rl(cs, l);
+                    if (sl != slot) {                     // next giant step (pairs are sorted by it)
+                        slot = sl;
+                        tb_load_async(x, a.ring, a.ring_size, idx, slot);   // once per giant step: waited for in full
+                        tb_wait<NL, 0>(x);
+                    }
+                    // rows of the pairs j+1 .. j+DEPTH-1 that exist were requested after this one
+                    const uint32_t newer = count - 1 - j;
+                    if (newer >= (uint32_t)(DEPTH - 1)) tb_wait_cnt<NL, DEPTH - 1>();
+                    else if (newer == 2) tb_wait_cnt<NL, (DEPTH > 2 ? 2 : DEPTH - 1)>();
+                    else if (newer == 1) tb_wait_cnt<NL, 1>();
+                    else tb_wait_cnt<NL, 0>();
+                    tb_tie<NL, 0, NL>(yq[d]);
+                    Fe<NL> t;
+                    fe_sub(t, x, yq[d], m);               // CROSS_PRODUCT_INV  ecm.c:1857-1859
+                    fe_mul(acc, acc, t, m);
+                    if (j + DEPTH < count) tb_load_async(yq[d], a.PbX, a.npb, idx, rl(ca, l));
                 }
-                Fe<NL> t;
-                fe_sub(t, x, yq[d], m);               // CROSS_PRODUCT_INV  ecm.c:1857-1859
-                fe_mul(acc, acc, t, m);
-                if (j + DEPTH < count) tb_load(yq[d], a.PbX, a.npb, idx, rb[d]);
             }
-        }
-#pragma unroll
-        for (int d = 0; d < DEPTH; d++) {
-            cs[d] = ns[d];
-            rb[d] = nr[d];
         }
     }
     Fe<NL> c;
