@@ -75,13 +75,15 @@ __device__ __forceinline__ void tb_store(uint32_t *__restrict__ base, uint32_t n
 // No "memory" clobber on these statements: the tables are read-only in the kernels that use them, and a clobber would
 // stop the compiler from fetching the wave-uniform tape words with scalar loads (its vector loads come with vmcnt(0)).
 #ifndef GECM_S2_ASYNC_MAXNL
-#define GECM_S2_ASYNC_MAXNL 16
+#define GECM_S2_ASYNC_MAXNL 30
 #endif
 template <int NL>
 __device__ __forceinline__ void tb_load_async(Fe<NL> &r, const uint32_t *__restrict__ base, uint32_t nent, uint32_t idx, size_t e)
 {
     // Only while every row in flight stays in registers: a row the compiler moves to scratch would be moved before it
-    // has arrived.  Larger residues keep compiler-visible loads.
+    // has arrived.  Larger residues keep compiler-visible loads.  tests/test_abi_cpu.py checks the built objects: the
+    // pair-walk kernels up to GECM_S2_ASYNC_MAXNL limbs use no scratch and spill nothing; tools/check_async_rows.py
+    // checks their ISA (no instruction but the loads touches a row register between request and wait).
     if constexpr (NL > GECM_S2_ASYNC_MAXNL) {
         tb_load(r, base, nent, idx, e);
         return;
@@ -755,6 +757,9 @@ __device__ __forceinline__ void giant_chunk_k(const S2PairArgs &a, uint32_t firs
 #ifndef GECM_S2_DEPTH
 #define GECM_S2_DEPTH 4
 #endif
+#ifndef GECM_S2_DEPTH_MAXNL
+#define GECM_S2_DEPTH_MAXNL 23            // above: two rows in flight (registers)
+#endif
 template <int NL>
 __device__ __forceinline__ void s2_pairs(const S2PairArgs &a, uint32_t first, uint32_t count, const S2Const<NL> &k,
                                          uint32_t idx, uint32_t *__restrict__ accbuf)
@@ -771,7 +776,7 @@ __device__ __forceinline__ void s2_pairs(const S2PairArgs &a, uint32_t first, ui
     // baby-step table comes from HBM instead of two rows (the walk is HBM-bound otherwise:
     // 2*60 B x 131,072 curves x 3.0 M pairs = 47 TB at B2 = 1e8).
     const uint32_t *st = a.steps + 2 * (size_t)first;
-    constexpr int DEPTH = GECM_S2_DEPTH;              // table rows in flight per lane
+    constexpr int DEPTH = NL <= GECM_S2_DEPTH_MAXNL ? GECM_S2_DEPTH : 2;     // table rows in flight per lane
     static_assert(64 % DEPTH == 0, "a block of 64 tape entries is walked in groups of DEPTH");
     Fe<NL> x, yq[DEPTH];
     // The tape is read 64 entries at a time, one entry per lane (coalesced), and handed out with v_readlane: `cs` =

@@ -287,3 +287,29 @@ def test_stage2_device_tape_follows_the_reference_s_batches(lib):
     tape, bad = Tape(), ctypes.c_uint32()
     assert lib.gecm_s2_tape_build(ctypes.byref(tape), ctypes.byref(plan), 4, z, z, 5, chunk, ring, ctypes.byref(bad)) == -2
     lib.gecm_s2_plan_free(ctypes.byref(plan))
+
+
+def test_pair_walk_kernels_with_hand_placed_loads_keep_their_rows_in_registers():
+    """gecm_stage2.hpp requests table rows with inline-asm loads up to GECM_S2_ASYNC_MAXNL limbs; that is only sound while
+    the compiler never moves a pending row to scratch.  Read the code objects of the built library's kernel objects: the
+    pair-walk kernels of those limb counts use no scratch and spill no register."""
+    import glob
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_resources
+    hdr = open(os.path.join(ROOT, "avx-ecm_amd", "csrc", "gecm_stage2.hpp")).read()
+    maxnl = int(re.search(r"#define GECM_S2_ASYNC_MAXNL (\d+)", hdr).group(1))
+    objs = glob.glob(os.path.join(ROOT, "avx-ecm_amd", "build", "gecm_kernels_*_p2.o"))
+    if not objs:
+        pytest.skip("no kernel objects (library built elsewhere)")
+    seen = 0
+    for o in objs:
+        nl = int(re.search(r"_(\d+)_p2", o).group(1))
+        if nl > maxnl:
+            continue
+        for name, vgpr, agpr, sgpr, scratch, spills in kernel_resources.kernels(o):
+            if "k_s2_pairs" in name:
+                seen += 1
+                assert scratch == 0 and spills == 0, (nl, name, scratch, spills)
+                assert vgpr <= 256
+    assert seen >= 10
