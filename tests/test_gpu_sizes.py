@@ -4,6 +4,7 @@ degenerate "factor already found" path.  Checks: L0 operators against Python int
 mathematical definition the reference's operators satisfy, verified in tests/golden/l0.json),
 stage 1 and stage 2 against the oracle."""
 import ctypes
+import math
 import os
 import random
 
@@ -79,6 +80,41 @@ def test_every_limb_count(orc, name, n, nl, digitbits):
         assert line.value.decode() == lines[k]
         orc.orc_stage2(c, sig[k], b1, b2, D, U, acch, None, 0, None)
         assert int(acch.value, 16) == acc[k]
+    orc.orc_destroy(c)
+
+
+@pytest.mark.parametrize("name,n,nl", CASES, ids=[c[0] for c in CASES])
+def test_pair_walk_long_segments_every_limb_count(orc, name, n, nl, monkeypatch):
+    """The pair walk in one slice per curve over segments of thousands of pairs: blocks of 64 tape entries, the rows in
+    flight across block boundaries and the tail of a segment, for every limb count (hand-placed loads with four or two
+    rows in flight, and the compiler-scheduled variant from 32 limbs on)."""
+    import pyecm
+    monkeypatch.setenv("GECM_S2_SLICES", "1")
+    rng = random.Random(nl)
+    sig = [rng.randrange(6, 1 << 63) for _ in range(65)]
+    b1, b2, D, U = 400, 400000, 2310, 8
+    eng = pyecm.Engine(n)
+    assert eng.cfg.dev_limbs == nl
+    eng.build_curves(sig)
+    eng.stage1(b1)
+    eng.stage2(b2, D, U)
+    acc = eng.download_acc()
+    st = eng.stage2_stats()
+    facs = {k: eng.stage2_factor(k) for k in (0, 1, 64)}
+    eng.close()
+    assert st.paired > 10000
+    c = orc.orc_create(str(n).encode(), 52)
+    acch = ctypes.create_string_buffer(8192)
+    fac = ctypes.create_string_buffer(4096)
+    for k in (0, 1, 64):
+        found = orc.orc_stage2(c, sig[k], b1, b2, D, U, acch, fac, len(fac), None)
+        if found:
+            # the composite with 2^17-1 and 2^31-1 in it: most curves find a factor.  The factor reported is the
+            # reference's; the accumulator itself is compared only when no inversion failed on the way (after a failed
+            # inversion the reference multiplies on with what mpz_invert left behind, which nobody defines)
+            assert facs[k][0] == int(fac.value)
+        if not found or math.gcd(int(acch.value, 16), n) == int(fac.value):
+            assert int(acch.value, 16) == acc[k]
     orc.orc_destroy(c)
 
 
