@@ -66,3 +66,13 @@ def test_gpus_must_match_world_size():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--no-engine"], env=env,
                        capture_output=True, text=True, timeout=120)
     assert p.returncode != 0 and "WORLD_SIZE" in p.stderr
+
+
+def test_committed_pmc_summary_is_for_the_headline_kernel():
+    """roofline.traffic comes from profiles/pmc_latest.json, and only when kernel, batch and B1 match the run: the
+    committed summary must be the one of the headline configuration's kernel (415-bit N: 15 limbs, 32 lanes per curve)."""
+    import json
+    pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
+    assert pm["kernel"] == _bench().kernel_name(32, 15)
+    assert pm["curves"] == 4096 and pm["B1"] == 1000000
+    assert pm["hbm_bytes_per_launch_corrected"] > 0
