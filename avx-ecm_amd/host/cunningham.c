@@ -69,86 +69,101 @@ static int two_pow_pm1(mpl_t *r, int x, int sign)
     return 0;
 }
 
+/* The primitive part of 2^e -/+ 1 (find_primitive_factor, main.c:187-353) by inclusion-exclusion over the distinct odd
+ * primes p_0 < ... < p_(r-1) of e:
+ *
+ *      prod over subsets S of { 2^(m * prod_{i in S} p_i) -/+ 1 }^((-1)^(r - |S|)),      m = e / (p_0 ... p_(r-1)).
+ *
+ * One enumeration does every r: subsets are listed by size, and within a size in lexicographic order of their index
+ * tuples.  Sizes of the parity of r multiply, largest first; then the other sizes divide, largest first.  That is also the
+ * order of the reference's "gen:" lines, which are reproduced here (the reference names the subsets of size k "rank k"
+ * and gives up beyond three distinct odd primes; so does this). */
+#define CUN_MAXP 3
+
+typedef struct {
+    int prod[1 << CUN_MAXP];      /* product of the chosen primes, subsets of one size after the other */
+    int first[CUN_MAXP + 2];      /* subsets of size k: prod[first[k]] .. prod[first[k+1]-1] */
+} cun_subsets;
+
+/* append the size-`want` subsets of p[from..r) that extend a partial product */
+static void subsets_of_size(cun_subsets *s, int *count, const int *p, int r, int from, int want, int partial)
+{
+    if (want == 0) {
+        s->prod[(*count)++] = partial;
+        return;
+    }
+    for (int i = from; i + want <= r; i++) subsets_of_size(s, count, p, r, i + 1, want - 1, partial * p[i]);
+}
+
+static int distinct_odd_primes_below_1000(int *p, int cap, int e)
+{
+    /* tdiv_int (main.c:163-184) walks the primes below 1000 in ascending order; only which odd ones divide e matters */
+    int r = 0;
+    for (int q = 3; q < 1000 && e > 1; q += 2) {
+        int prime = 1;
+        for (int d = 3; d * d <= q; d += 2)
+            if (q % d == 0) { prime = 0; break; }
+        if (!prime || e % q) continue;
+        while (e % q == 0) e /= q;
+        if (r < cap) p[r] = q;
+        r++;
+    }
+    return r;
+}
+
 int cunningham_primitive(mpl_t *prim, int e, int sign, char *log, size_t loglen)
 {
-    /* tdiv_int (main.c:163-184): prime factors of e below 1000, with multiplicity, ascending */
-    int f[32], nf = 0;
-    {
-        int xx = e, q = 2;
-        while (xx > 1 && q < 1000) {
-            int isp = 1;
-            for (int d = 2; d * d <= q; d++)
-                if (q % d == 0) { isp = 0; break; }
-            if (!isp || xx % q != 0) { q++; continue; }
-            xx /= q;
-            if (nf < 32) f[nf++] = q;
-        }
-    }
-    int franks[4][32], cranks[4] = {1, 0, 0, 0};
-    franks[0][0] = 1;
-    int j = 0;
+    int p[32];
+    const int r = distinct_odd_primes_below_1000(p, 32, e);
     logf_(log, loglen, "gen: rank 1 terms: ");
-    for (int i = 0; i < nf; i++)
-        if ((f[i] & 1) && (j == 0 || f[i] != franks[1][j - 1])) {
-            franks[1][j++] = f[i];
-            logf_(log, loglen, "%d ", f[i]);
-        }
+    for (int i = 0; i < r && i < 32; i++) logf_(log, loglen, "%d ", p[i]);
     logf_(log, loglen, "\n");
-    cranks[1] = j;
-    const int nr = j + 1;
-    if (j > 3) {
+    if (r > CUN_MAXP) {
         logf_(log, loglen, "gen: too many distinct odd factors in exponent!\n");
         return -1;
     }
-    if (cranks[1] == 2) {
-        franks[2][0] = franks[1][0] * franks[1][1];
-        cranks[2] = 1;
-        logf_(log, loglen, "gen: rank 2 term: %d\n", franks[2][0]);
-    } else if (cranks[1] == 3) {
-        int m = 0;
-        logf_(log, loglen, "gen: rank 2 terms: ");
-        for (int a = 0; a < 2; a++)
-            for (int b = a + 1; b < 3; b++) {
-                franks[2][m++] = franks[1][a] * franks[1][b];
-                logf_(log, loglen, "%d ", franks[2][m - 1]);
-            }
-        cranks[2] = m;
-        logf_(log, loglen, "\n");
-        franks[3][0] = franks[1][0] * franks[1][1] * franks[1][2];
-        cranks[3] = 1;
-        logf_(log, loglen, "gen: rank 3 term: %d\n", franks[3][0]);
+    cun_subsets s;
+    int count = 0, m = e;
+    for (int k = 0; k <= r; k++) {
+        s.first[k] = count;
+        subsets_of_size(&s, &count, p, r, 0, k, 1);
     }
-    int mult = e;
-    for (int i = 0; i < cranks[1]; i++) mult /= franks[1][i];
-    logf_(log, loglen, "gen: base exponent multiplier: %d\n", mult);
+    s.first[r + 1] = count;
+    for (int k = 2; k <= r; k++) {
+        const int n = s.first[k + 1] - s.first[k];
+        if (n == 1) {
+            logf_(log, loglen, "gen: rank %d term: %d\n", k, s.prod[s.first[k]]);
+            continue;
+        }
+        logf_(log, loglen, "gen: rank %d terms: ", k);
+        for (int t = s.first[k]; t < s.first[k + 1]; t++) logf_(log, loglen, "%d ", s.prod[t]);
+        logf_(log, loglen, "\n");
+    }
+    for (int i = 0; i < r; i++) m /= p[i];
+    logf_(log, loglen, "gen: base exponent multiplier: %d\n", m);
 
     static char dec[MPL_MAXL * 10 + 16];
-    mpl_t n, term, rem, q;
-    mpl_set_u64(&n, 1);
-    const int mrank = (nr & 1) ? 0 : 1;
-    const char c = sign > 0 ? '-' : '+';
-    for (int i = nr - 1; i >= 0; i--) {
-        if ((i & 1) != mrank) continue;
-        for (int k = 0; k < cranks[i]; k++) {
-            if (two_pow_pm1(&term, franks[i][k] * mult, sign)) return -1;
-            mpl_get_dec(dec, &term);
-            logf_(log, loglen, "gen: multiplying by %d^%d %c 1 = %s\n", 2, franks[i][k] * mult, c, dec);
-            if (n.n + term.n > MPL_MAXL - 2) return -1;
-            mpl_mul(&n, &n, &term);
+    mpl_t acc, term, quo, rem;
+    mpl_set_u64(&acc, 1);
+    for (int pass = 0; pass < 2; pass++)                     /* 0: the factors of the numerator, 1: of the denominator */
+        for (int k = r; k >= 0; k--) {
+            if (((r - k) & 1) != pass) continue;
+            for (int t = s.first[k]; t < s.first[k + 1]; t++) {
+                const int x = s.prod[t] * m;
+                if (two_pow_pm1(&term, x, sign)) return -1;
+                mpl_get_dec(dec, &term);
+                logf_(log, loglen, "gen: %s by 2^%d %c 1 = %s\n", pass ? "dividing" : "multiplying", x, sign > 0 ? '-' : '+', dec);
+                if (!pass) {
+                    if (acc.n + term.n > MPL_MAXL - 2) return -1;
+                    mpl_mul(&acc, &acc, &term);
+                    continue;
+                }
+                mpl_divrem(&quo, &rem, &acc, &term);
+                if (!mpl_is_zero(&rem)) logf_(log, loglen, "gen: error, term doesn't divide n!\n");
+                else acc = quo;
+            }
         }
-    }
-    for (int i = nr - 1; i >= 0; i--) {
-        if ((i & 1) == mrank) continue;
-        for (int k = 0; k < cranks[i]; k++) {
-            if (two_pow_pm1(&term, franks[i][k] * mult, sign)) return -1;
-            mpl_get_dec(dec, &term);
-            logf_(log, loglen, "gen: dividing by %d^%d %c 1 = %s\n", 2, franks[i][k] * mult, c, dec);
-            mpl_divrem(&q, &rem, &n, &term);
-            if (!mpl_is_zero(&rem)) logf_(log, loglen, "gen: error, term doesn't divide n!\n");
-            else n = q;
-        }
-    }
-    *prim = n;
+    *prim = acc;
     return 0;
 }
 
