@@ -78,3 +78,55 @@ def test_all_stage1_kernel_flavours_write_the_oracles_lines(orc, name, n, b1, si
             assert eng.lanes_per_curve() == lanes and eng.special_form_used() == special
             assert eng.save_lines() == want, (name, special, lanes)
     eng.close()
+
+
+def _s2_cases():
+    """Stage 2: moduli without small factors (products of Mersenne primes, so that no inversion fails and the
+    accumulator is defined by the reference's arithmetic alone), random B1 < B2, every wheel, table sizes U = 1 .. 16, the
+    pair walk in one slice or in the library's choice of slices, K sub-sequences or the plain chain."""
+    rng = random.Random(20261005)
+    M = {e: (1 << e) - 1 for e in (61, 89, 107, 127, 521, 607)}
+    mods = [M[127] * M[89], M[127] * M[107] * M[89] * M[61], M[521], M[521] * M[127], M[607] * M[127] * M[89],
+            M[607] * M[127] * M[107] * M[89] * M[61], M[521] * M[107] * M[89]]
+    out = []
+    for i in range(28):
+        n = mods[i % len(mods)]
+        b1 = rng.randrange(50, 3000)
+        D = rng.choice((210, 385, 2310))
+        U = rng.randrange(1, 17)
+        b2 = b1 + rng.randrange(1000, 40 * D * U + 20000)
+        env = {}
+        if rng.random() < 0.5:
+            env["GECM_S2_SLICES"] = "1"
+        if rng.random() < 0.3:
+            env["GECM_S2_SUBSEQ"] = str(rng.choice((1, 2, 4)))
+        out.append((n, b1, b2, D, U, rng.randrange(6, 1 << 62), rng.choice((1, 64, 65, 130)), env))
+    return out
+
+
+S2_CASES = _s2_cases()
+
+
+@pytest.mark.parametrize("n,b1,b2,D,U,sigma0,batch,env", S2_CASES,
+                         ids=["%02d_%dbit_B2_%d_D%d_U%d%s" % (i, c[0].bit_length(), c[2], c[3], c[4], "_" + "_".join(sorted(c[7])) if c[7] else "")
+                              for i, c in enumerate(S2_CASES)])
+def test_stage2_accumulators_on_random_parameters(orc, n, b1, b2, D, U, sigma0, batch, env, monkeypatch):
+    import pyecm
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    orc.orc_stage2.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32,
+                               ctypes.c_uint32, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t,
+                               ctypes.POINTER(ctypes.c_uint64)]
+    sig = [sigma0 + k for k in range(batch)]
+    eng = pyecm.Engine(n)
+    eng.build_curves(sig)
+    eng.stage1(b1)
+    eng.stage2(b2, D, U)
+    acc = eng.download_acc()
+    eng.close()
+    c = orc.orc_create(str(n).encode(), 52)
+    acch = ctypes.create_string_buffer(8192)
+    for k in sorted({0, batch // 2, batch - 1}):
+        orc.orc_stage2(c, sig[k], b1, b2, D, U, acch, None, 0, None)
+        assert int(acch.value, 16) == acc[k], (k, b1, b2, D, U, env)
+    orc.orc_destroy(c)
