@@ -31,6 +31,10 @@ static const int k_supported_nl[] = {
     0};
 extern "C" const int *gecm_dev_supported_nl(void) { return k_supported_nl; }
 
+#ifndef GECM_S2_WAVES_PER_SIMD
+#define GECM_S2_WAVES_PER_SIMD 16         // wavefronts per SIMD a pair-walk launch is cut up for (gecm_dev_s2_init)
+#endif
+#define GECM_S2_MAX_SLICES 64
 struct gecm_dev {
     int device = 0;
     int nl = 0;
@@ -484,16 +488,20 @@ extern "C" int gecm_dev_s2_init(gecm_dev *d, const uint32_t *keep, size_t keep_w
         HIPCHK(hipMalloc(&d->dPbX, coord * npb));
         HIPCHK(hipMalloc(&d->dBlk, coord * 3 * GECM_S2_BLK));    // bx, bz, bp: S2_BLK entries each
         HIPCHK(hipMalloc(&d->dPd, coord * 2));
-        // The pair walk is a product, so a batch that cannot fill the chip with one wavefront per 64
-        // curves walks each run of pairs in `slices` parts (one more grid dimension, one accumulator
-        // each) until there are 2 wavefronts per SIMD; slice 0 is the accumulator everyone else sees.
+        // The pair walk is a product, so each run of pairs is walked in `slices` parts (one more grid dimension, one
+        // accumulator each; slice 0 is the accumulator everyone else sees) until the launch has GECM_S2_WAVES_PER_SIMD
+        // wavefronts for every SIMD.  Two per SIMD is what it takes to issue a multiply-add every 4.7 cycles, but the
+        // walk also waits for table rows, and its 160 registers let three wavefronts share a SIMD: the full batch
+        // (2048 wavefronts) went from 8.26 s to 7.68 s per 1e8 range with 4 slices, 7.57 s with 8; 32,768 curves from
+        // 2.04 s (8 slices) to 1.96 s (32); 4096 curves from 0.380 s (32) to 0.371 s (64)
+        // (profiles/r02_stage2_slices.txt).
         {
-            const size_t waves = d->stride / 64, want = (size_t)d->cus * 4 * 2;
-            size_t p = waves ? want / waves : 1;
-            d->s2_slices = (uint32_t)(p < 1 ? 1 : p > 32 ? 32 : p);
+            const size_t waves = d->stride / 64, want = (size_t)d->cus * 4 * GECM_S2_WAVES_PER_SIMD;
+            size_t p = waves ? (want + waves - 1) / waves : 1;
+            d->s2_slices = (uint32_t)(p < 1 ? 1 : p > GECM_S2_MAX_SLICES ? GECM_S2_MAX_SLICES : p);
             if (const char *e = getenv("GECM_S2_SLICES")) {      // measurement knob (tools/s2_small.py)
                 const long v = strtol(e, nullptr, 10);
-                if (v >= 1 && v <= 32) d->s2_slices = (uint32_t)v;
+                if (v >= 1 && v <= GECM_S2_MAX_SLICES) d->s2_slices = (uint32_t)v;
             }
         }
         HIPCHK(hipMalloc(&d->dAcc, coord * d->s2_slices));
