@@ -57,107 +57,68 @@ struct Fe {
 #define GECM_MAD_CHUNK 14     // mads per asm statement (<= 14: an asm statement takes at most 30 operands)
 #endif
 
+// The statements for K = 1 .. 14 multiply-adds are spelled by the preprocessor: GECM_MAD_TEXT_k is the text of k
+// instructions (operands %1,%2 / %3,%4 / ...), GECM_MAD_OPS_k(Y) their operand list with constraint Y on the second
+// factor ("v": a register per lane, "s": a wave-uniform value read straight from an SGPR).
+#define GECM_MAD_LINE(a, b) "v_mad_u64_u32 %0, vcc, %" #a ", %" #b ", %0\n\t"
+#define GECM_MAD_TEXT_1 GECM_MAD_LINE(1, 2)
+#define GECM_MAD_TEXT_2 GECM_MAD_TEXT_1 GECM_MAD_LINE(3, 4)
+#define GECM_MAD_TEXT_3 GECM_MAD_TEXT_2 GECM_MAD_LINE(5, 6)
+#define GECM_MAD_TEXT_4 GECM_MAD_TEXT_3 GECM_MAD_LINE(7, 8)
+#define GECM_MAD_TEXT_5 GECM_MAD_TEXT_4 GECM_MAD_LINE(9, 10)
+#define GECM_MAD_TEXT_6 GECM_MAD_TEXT_5 GECM_MAD_LINE(11, 12)
+#define GECM_MAD_TEXT_7 GECM_MAD_TEXT_6 GECM_MAD_LINE(13, 14)
+#define GECM_MAD_TEXT_8 GECM_MAD_TEXT_7 GECM_MAD_LINE(15, 16)
+#define GECM_MAD_TEXT_9 GECM_MAD_TEXT_8 GECM_MAD_LINE(17, 18)
+#define GECM_MAD_TEXT_10 GECM_MAD_TEXT_9 GECM_MAD_LINE(19, 20)
+#define GECM_MAD_TEXT_11 GECM_MAD_TEXT_10 GECM_MAD_LINE(21, 22)
+#define GECM_MAD_TEXT_12 GECM_MAD_TEXT_11 GECM_MAD_LINE(23, 24)
+#define GECM_MAD_TEXT_13 GECM_MAD_TEXT_12 GECM_MAD_LINE(25, 26)
+#define GECM_MAD_TEXT_14 GECM_MAD_TEXT_13 GECM_MAD_LINE(27, 28)
+#define GECM_MAD_OPS_1(Y) "v"(x[0]), Y(y[0])
+#define GECM_MAD_OPS_2(Y) GECM_MAD_OPS_1(Y), "v"(x[1]), Y(y[1])
+#define GECM_MAD_OPS_3(Y) GECM_MAD_OPS_2(Y), "v"(x[2]), Y(y[2])
+#define GECM_MAD_OPS_4(Y) GECM_MAD_OPS_3(Y), "v"(x[3]), Y(y[3])
+#define GECM_MAD_OPS_5(Y) GECM_MAD_OPS_4(Y), "v"(x[4]), Y(y[4])
+#define GECM_MAD_OPS_6(Y) GECM_MAD_OPS_5(Y), "v"(x[5]), Y(y[5])
+#define GECM_MAD_OPS_7(Y) GECM_MAD_OPS_6(Y), "v"(x[6]), Y(y[6])
+#define GECM_MAD_OPS_8(Y) GECM_MAD_OPS_7(Y), "v"(x[7]), Y(y[7])
+#define GECM_MAD_OPS_9(Y) GECM_MAD_OPS_8(Y), "v"(x[8]), Y(y[8])
+#define GECM_MAD_OPS_10(Y) GECM_MAD_OPS_9(Y), "v"(x[9]), Y(y[9])
+#define GECM_MAD_OPS_11(Y) GECM_MAD_OPS_10(Y), "v"(x[10]), Y(y[10])
+#define GECM_MAD_OPS_12(Y) GECM_MAD_OPS_11(Y), "v"(x[11]), Y(y[11])
+#define GECM_MAD_OPS_13(Y) GECM_MAD_OPS_12(Y), "v"(x[12]), Y(y[12])
+#define GECM_MAD_OPS_14(Y) GECM_MAD_OPS_13(Y), "v"(x[13]), Y(y[13])
+#define GECM_MAD_CASE(k, Y) \
+    if constexpr (K == k) asm(GECM_MAD_TEXT_##k : "+v"(acc) : GECM_MAD_OPS_##k(Y) : "vcc");
+#define GECM_MAD_CASES(Y)                                                                                              \
+    GECM_MAD_CASE(1, Y) GECM_MAD_CASE(2, Y) GECM_MAD_CASE(3, Y) GECM_MAD_CASE(4, Y) GECM_MAD_CASE(5, Y)                    \
+    GECM_MAD_CASE(6, Y) GECM_MAD_CASE(7, Y) GECM_MAD_CASE(8, Y) GECM_MAD_CASE(9, Y) GECM_MAD_CASE(10, Y)                   \
+    GECM_MAD_CASE(11, Y) GECM_MAD_CASE(12, Y) GECM_MAD_CASE(13, Y) GECM_MAD_CASE(14, Y)
+
+// acc += sum x[k] * y[k], both factors in vector registers
 template <int K>
 __device__ __forceinline__ void mad_chain_v(uint64_t &acc, const uint32_t (&x)[K], const uint32_t (&y)[K])
 {
+    static_assert(K >= 1 && K <= 14, "one asm statement takes at most 30 operands");
 #ifdef GECM_CXX_MAD
 #pragma unroll
     for (int k = 0; k < K; k++) acc += (uint64_t)x[k] * (uint64_t)y[k];
 #else
-    if constexpr (K == 1) {
-        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(x[0]), "v"(y[0]) : "vcc");
-    }
-    else if constexpr (K == 2) {
-        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %3, %4, %0" : "+v"(acc) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]) : "vcc");
-    }
-    else if constexpr (K == 3) {
-        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_mad_u64_u32 %0, vcc, %5, %6, %0" : "+v"(acc) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]) : "vcc");
-    }
-    else if constexpr (K == 4) {
-        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_mad_u64_u32 %0, vcc, %5, %6, %0\n\tv_mad_u64_u32 %0, vcc, %7, %8, %0" : "+v"(acc) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]) : "vcc");
-    }
-    else if constexpr (K == 5) {
-        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_mad_u64_u32 %0, vcc, %5, %6, %0\n\tv_mad_u64_u32 %0, vcc, %7, %8, %0\n\tv_mad_u64_u32 %0, vcc, %9, %10, %0" : "+v"(acc) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]) : "vcc");
-    }
-    else if constexpr (K == 6) {
-        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_mad_u64_u32 %0, vcc, %5, %6, %0\n\tv_mad_u64_u32 %0, vcc, %7, %8, %0\n\tv_mad_u64_u32 %0, vcc, %9, %10, %0\n\tv_mad_u64_u32 %0, vcc, %11, %12, %0" : "+v"(acc) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]) : "vcc");
-    }
-    else if constexpr (K == 7) {
-        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_mad_u64_u32 %0, vcc, %5, %6, %0\n\tv_mad_u64_u32 %0, vcc, %7, %8, %0\n\tv_mad_u64_u32 %0, vcc, %9, %10, %0\n\tv_mad_u64_u32 %0, vcc, %11, %12, %0\n\tv_mad_u64_u32 %0, vcc, %13, %14, %0" : "+v"(acc) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]) : "vcc");
-    }
-    else if constexpr (K == 8) {
-        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_mad_u64_u32 %0, vcc, %5, %6, %0\n\tv_mad_u64_u32 %0, vcc, %7, %8, %0\n\tv_mad_u64_u32 %0, vcc, %9, %10, %0\n\tv_mad_u64_u32 %0, vcc, %11, %12, %0\n\tv_mad_u64_u32 %0, vcc, %13, %14, %0\n\tv_mad_u64_u32 %0, vcc, %15, %16, %0" : "+v"(acc) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]), "v"(x[7]), "v"(y[7]) : "vcc");
-    }
-    else if constexpr (K == 9) {
-        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_mad_u64_u32 %0, vcc, %5, %6, %0\n\tv_mad_u64_u32 %0, vcc, %7, %8, %0\n\tv_mad_u64_u32 %0, vcc, %9, %10, %0\n\tv_mad_u64_u32 %0, vcc, %11, %12, %0\n\tv_mad_u64_u32 %0, vcc, %13, %14, %0\n\tv_mad_u64_u32 %0, vcc, %15, %16, %0\n\tv_mad_u64_u32 %0, vcc, %17, %18, %0" : "+v"(acc) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]), "v"(x[7]), "v"(y[7]), "v"(x[8]), "v"(y[8]) : "vcc");
-    }
-    else if constexpr (K == 10) {
-        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_mad_u64_u32 %0, vcc, %5, %6, %0\n\tv_mad_u64_u32 %0, vcc, %7, %8, %0\n\tv_mad_u64_u32 %0, vcc, %9, %10, %0\n\tv_mad_u64_u32 %0, vcc, %11, %12, %0\n\tv_mad_u64_u32 %0, vcc, %13, %14, %0\n\tv_mad_u64_u32 %0, vcc, %15, %16, %0\n\tv_mad_u64_u32 %0, vcc, %17, %18, %0\n\tv_mad_u64_u32 %0, vcc, %19, %20, %0" : "+v"(acc) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]), "v"(x[7]), "v"(y[7]), "v"(x[8]), "v"(y[8]), "v"(x[9]), "v"(y[9]) : "vcc");
-    }
-    else if constexpr (K == 11) {
-        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_mad_u64_u32 %0, vcc, %5, %6, %0\n\tv_mad_u64_u32 %0, vcc, %7, %8, %0\n\tv_mad_u64_u32 %0, vcc, %9, %10, %0\n\tv_mad_u64_u32 %0, vcc, %11, %12, %0\n\tv_mad_u64_u32 %0, vcc, %13, %14, %0\n\tv_mad_u64_u32 %0, vcc, %15, %16, %0\n\tv_mad_u64_u32 %0, vcc, %17, %18, %0\n\tv_mad_u64_u32 %0, vcc, %19, %20, %0\n\tv_mad_u64_u32 %0, vcc, %21, %22, %0" : "+v"(acc) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]), "v"(x[7]), "v"(y[7]), "v"(x[8]), "v"(y[8]), "v"(x[9]), "v"(y[9]), "v"(x[10]), "v"(y[10]) : "vcc");
-    }
-    else if constexpr (K == 12) {
-        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_mad_u64_u32 %0, vcc, %5, %6, %0\n\tv_mad_u64_u32 %0, vcc, %7, %8, %0\n\tv_mad_u64_u32 %0, vcc, %9, %10, %0\n\tv_mad_u64_u32 %0, vcc, %11, %12, %0\n\tv_mad_u64_u32 %0, vcc, %13, %14, %0\n\tv_mad_u64_u32 %0, vcc, %15, %16, %0\n\tv_mad_u64_u32 %0, vcc, %17, %18, %0\n\tv_mad_u64_u32 %0, vcc, %19, %20, %0\n\tv_mad_u64_u32 %0, vcc, %21, %22, %0\n\tv_mad_u64_u32 %0, vcc, %23, %24, %0" : "+v"(acc) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]), "v"(x[7]), "v"(y[7]), "v"(x[8]), "v"(y[8]), "v"(x[9]), "v"(y[9]), "v"(x[10]), "v"(y[10]), "v"(x[11]), "v"(y[11]) : "vcc");
-    }
-    else if constexpr (K == 13) {
-        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_mad_u64_u32 %0, vcc, %5, %6, %0\n\tv_mad_u64_u32 %0, vcc, %7, %8, %0\n\tv_mad_u64_u32 %0, vcc, %9, %10, %0\n\tv_mad_u64_u32 %0, vcc, %11, %12, %0\n\tv_mad_u64_u32 %0, vcc, %13, %14, %0\n\tv_mad_u64_u32 %0, vcc, %15, %16, %0\n\tv_mad_u64_u32 %0, vcc, %17, %18, %0\n\tv_mad_u64_u32 %0, vcc, %19, %20, %0\n\tv_mad_u64_u32 %0, vcc, %21, %22, %0\n\tv_mad_u64_u32 %0, vcc, %23, %24, %0\n\tv_mad_u64_u32 %0, vcc, %25, %26, %0" : "+v"(acc) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]), "v"(x[7]), "v"(y[7]), "v"(x[8]), "v"(y[8]), "v"(x[9]), "v"(y[9]), "v"(x[10]), "v"(y[10]), "v"(x[11]), "v"(y[11]), "v"(x[12]), "v"(y[12]) : "vcc");
-    }
-    else if constexpr (K == 14) {
-        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_mad_u64_u32 %0, vcc, %5, %6, %0\n\tv_mad_u64_u32 %0, vcc, %7, %8, %0\n\tv_mad_u64_u32 %0, vcc, %9, %10, %0\n\tv_mad_u64_u32 %0, vcc, %11, %12, %0\n\tv_mad_u64_u32 %0, vcc, %13, %14, %0\n\tv_mad_u64_u32 %0, vcc, %15, %16, %0\n\tv_mad_u64_u32 %0, vcc, %17, %18, %0\n\tv_mad_u64_u32 %0, vcc, %19, %20, %0\n\tv_mad_u64_u32 %0, vcc, %21, %22, %0\n\tv_mad_u64_u32 %0, vcc, %23, %24, %0\n\tv_mad_u64_u32 %0, vcc, %25, %26, %0\n\tv_mad_u64_u32 %0, vcc, %27, %28, %0" : "+v"(acc) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]), "v"(x[7]), "v"(y[7]), "v"(x[8]), "v"(y[8]), "v"(x[9]), "v"(y[9]), "v"(x[10]), "v"(y[10]), "v"(x[11]), "v"(y[11]), "v"(x[12]), "v"(y[12]), "v"(x[13]), "v"(y[13]) : "vcc");
-    }
+    GECM_MAD_CASES("v")
 #endif
 }
 
+// the same with wave-uniform y[k] (limbs of the modulus)
 template <int K>
 __device__ __forceinline__ void mad_chain_s(uint64_t &acc, const uint32_t (&x)[K], const uint32_t (&y)[K])
 {
+    static_assert(K >= 1 && K <= 14, "one asm statement takes at most 30 operands");
 #ifdef GECM_CXX_MAD
 #pragma unroll
     for (int k = 0; k < K; k++) acc += (uint64_t)x[k] * (uint64_t)y[k];
 #else
-    if constexpr (K == 1) {
-        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(x[0]), "s"(y[0]) : "vcc");
-    }
-    else if constexpr (K == 2) {
-        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %3, %4, %0" : "+v"(acc) : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]) : "vcc");
-    }
-    else if constexpr (K == 3) {
-        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_mad_u64_u32 %0, vcc, %5, %6, %0" : "+v"(acc) : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]) : "vcc");
-    }
-    else if constexpr (K == 4) {
-        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_mad_u64_u32 %0, vcc, %5, %6, %0\n\tv_mad_u64_u32 %0, vcc, %7, %8, %0" : "+v"(acc) : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]) : "vcc");
-    }
-    else if constexpr (K == 5) {
-        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_mad_u64_u32 %0, vcc, %5, %6, %0\n\tv_mad_u64_u32 %0, vcc, %7, %8, %0\n\tv_mad_u64_u32 %0, vcc, %9, %10, %0" : "+v"(acc) : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]), "v"(x[4]), "s"(y[4]) : "vcc");
-    }
-    else if constexpr (K == 6) {
-        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_mad_u64_u32 %0, vcc, %5, %6, %0\n\tv_mad_u64_u32 %0, vcc, %7, %8, %0\n\tv_mad_u64_u32 %0, vcc, %9, %10, %0\n\tv_mad_u64_u32 %0, vcc, %11, %12, %0" : "+v"(acc) : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]), "v"(x[4]), "s"(y[4]), "v"(x[5]), "s"(y[5]) : "vcc");
-    }
-    else if constexpr (K == 7) {
-        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_mad_u64_u32 %0, vcc, %5, %6, %0\n\tv_mad_u64_u32 %0, vcc, %7, %8, %0\n\tv_mad_u64_u32 %0, vcc, %9, %10, %0\n\tv_mad_u64_u32 %0, vcc, %11, %12, %0\n\tv_mad_u64_u32 %0, vcc, %13, %14, %0" : "+v"(acc) : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]), "v"(x[4]), "s"(y[4]), "v"(x[5]), "s"(y[5]), "v"(x[6]), "s"(y[6]) : "vcc");
-    }
-    else if constexpr (K == 8) {
-        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_mad_u64_u32 %0, vcc, %5, %6, %0\n\tv_mad_u64_u32 %0, vcc, %7, %8, %0\n\tv_mad_u64_u32 %0, vcc, %9, %10, %0\n\tv_mad_u64_u32 %0, vcc, %11, %12, %0\n\tv_mad_u64_u32 %0, vcc, %13, %14, %0\n\tv_mad_u64_u32 %0, vcc, %15, %16, %0" : "+v"(acc) : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]), "v"(x[4]), "s"(y[4]), "v"(x[5]), "s"(y[5]), "v"(x[6]), "s"(y[6]), "v"(x[7]), "s"(y[7]) : "vcc");
-    }
-    else if constexpr (K == 9) {
-        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_mad_u64_u32 %0, vcc, %5, %6, %0\n\tv_mad_u64_u32 %0, vcc, %7, %8, %0\n\tv_mad_u64_u32 %0, vcc, %9, %10, %0\n\tv_mad_u64_u32 %0, vcc, %11, %12, %0\n\tv_mad_u64_u32 %0, vcc, %13, %14, %0\n\tv_mad_u64_u32 %0, vcc, %15, %16, %0\n\tv_mad_u64_u32 %0, vcc, %17, %18, %0" : "+v"(acc) : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]), "v"(x[4]), "s"(y[4]), "v"(x[5]), "s"(y[5]), "v"(x[6]), "s"(y[6]), "v"(x[7]), "s"(y[7]), "v"(x[8]), "s"(y[8]) : "vcc");
-    }
-    else if constexpr (K == 10) {
-        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_mad_u64_u32 %0, vcc, %5, %6, %0\n\tv_mad_u64_u32 %0, vcc, %7, %8, %0\n\tv_mad_u64_u32 %0, vcc, %9, %10, %0\n\tv_mad_u64_u32 %0, vcc, %11, %12, %0\n\tv_mad_u64_u32 %0, vcc, %13, %14, %0\n\tv_mad_u64_u32 %0, vcc, %15, %16, %0\n\tv_mad_u64_u32 %0, vcc, %17, %18, %0\n\tv_mad_u64_u32 %0, vcc, %19, %20, %0" : "+v"(acc) : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]), "v"(x[4]), "s"(y[4]), "v"(x[5]), "s"(y[5]), "v"(x[6]), "s"(y[6]), "v"(x[7]), "s"(y[7]), "v"(x[8]), "s"(y[8]), "v"(x[9]), "s"(y[9]) : "vcc");
-    }
-    else if constexpr (K == 11) {
-        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_mad_u64_u32 %0, vcc, %5, %6, %0\n\tv_mad_u64_u32 %0, vcc, %7, %8, %0\n\tv_mad_u64_u32 %0, vcc, %9, %10, %0\n\tv_mad_u64_u32 %0, vcc, %11, %12, %0\n\tv_mad_u64_u32 %0, vcc, %13, %14, %0\n\tv_mad_u64_u32 %0, vcc, %15, %16, %0\n\tv_mad_u64_u32 %0, vcc, %17, %18, %0\n\tv_mad_u64_u32 %0, vcc, %19, %20, %0\n\tv_mad_u64_u32 %0, vcc, %21, %22, %0" : "+v"(acc) : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]), "v"(x[4]), "s"(y[4]), "v"(x[5]), "s"(y[5]), "v"(x[6]), "s"(y[6]), "v"(x[7]), "s"(y[7]), "v"(x[8]), "s"(y[8]), "v"(x[9]), "s"(y[9]), "v"(x[10]), "s"(y[10]) : "vcc");
-    }
-    else if constexpr (K == 12) {
-        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_mad_u64_u32 %0, vcc, %5, %6, %0\n\tv_mad_u64_u32 %0, vcc, %7, %8, %0\n\tv_mad_u64_u32 %0, vcc, %9, %10, %0\n\tv_mad_u64_u32 %0, vcc, %11, %12, %0\n\tv_mad_u64_u32 %0, vcc, %13, %14, %0\n\tv_mad_u64_u32 %0, vcc, %15, %16, %0\n\tv_mad_u64_u32 %0, vcc, %17, %18, %0\n\tv_mad_u64_u32 %0, vcc, %19, %20, %0\n\tv_mad_u64_u32 %0, vcc, %21, %22, %0\n\tv_mad_u64_u32 %0, vcc, %23, %24, %0" : "+v"(acc) : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]), "v"(x[4]), "s"(y[4]), "v"(x[5]), "s"(y[5]), "v"(x[6]), "s"(y[6]), "v"(x[7]), "s"(y[7]), "v"(x[8]), "s"(y[8]), "v"(x[9]), "s"(y[9]), "v"(x[10]), "s"(y[10]), "v"(x[11]), "s"(y[11]) : "vcc");
-    }
-    else if constexpr (K == 13) {
-        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_mad_u64_u32 %0, vcc, %5, %6, %0\n\tv_mad_u64_u32 %0, vcc, %7, %8, %0\n\tv_mad_u64_u32 %0, vcc, %9, %10, %0\n\tv_mad_u64_u32 %0, vcc, %11, %12, %0\n\tv_mad_u64_u32 %0, vcc, %13, %14, %0\n\tv_mad_u64_u32 %0, vcc, %15, %16, %0\n\tv_mad_u64_u32 %0, vcc, %17, %18, %0\n\tv_mad_u64_u32 %0, vcc, %19, %20, %0\n\tv_mad_u64_u32 %0, vcc, %21, %22, %0\n\tv_mad_u64_u32 %0, vcc, %23, %24, %0\n\tv_mad_u64_u32 %0, vcc, %25, %26, %0" : "+v"(acc) : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]), "v"(x[4]), "s"(y[4]), "v"(x[5]), "s"(y[5]), "v"(x[6]), "s"(y[6]), "v"(x[7]), "s"(y[7]), "v"(x[8]), "s"(y[8]), "v"(x[9]), "s"(y[9]), "v"(x[10]), "s"(y[10]), "v"(x[11]), "s"(y[11]), "v"(x[12]), "s"(y[12]) : "vcc");
-    }
-    else if constexpr (K == 14) {
-        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_mad_u64_u32 %0, vcc, %5, %6, %0\n\tv_mad_u64_u32 %0, vcc, %7, %8, %0\n\tv_mad_u64_u32 %0, vcc, %9, %10, %0\n\tv_mad_u64_u32 %0, vcc, %11, %12, %0\n\tv_mad_u64_u32 %0, vcc, %13, %14, %0\n\tv_mad_u64_u32 %0, vcc, %15, %16, %0\n\tv_mad_u64_u32 %0, vcc, %17, %18, %0\n\tv_mad_u64_u32 %0, vcc, %19, %20, %0\n\tv_mad_u64_u32 %0, vcc, %21, %22, %0\n\tv_mad_u64_u32 %0, vcc, %23, %24, %0\n\tv_mad_u64_u32 %0, vcc, %25, %26, %0\n\tv_mad_u64_u32 %0, vcc, %27, %28, %0" : "+v"(acc) : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]), "v"(x[4]), "s"(y[4]), "v"(x[5]), "s"(y[5]), "v"(x[6]), "s"(y[6]), "v"(x[7]), "s"(y[7]), "v"(x[8]), "s"(y[8]), "v"(x[9]), "s"(y[9]), "v"(x[10]), "s"(y[10]), "v"(x[11]), "s"(y[11]), "v"(x[12]), "s"(y[12]), "v"(x[13]), "s"(y[13]) : "vcc");
-    }
+    GECM_MAD_CASES("s")
 #endif
 }
 
