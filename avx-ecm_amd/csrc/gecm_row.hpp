@@ -366,7 +366,7 @@ __device__ __forceinline__ void stage1_row(const uint32_t *__restrict__ tape, ui
                                            uint32_t *__restrict__ Z, const uint32_t *__restrict__ S, size_t stride,
                                            uint32_t nl, const uint32_t *__restrict__ rc, uint32_t rho_n)
 {
-    const uint32_t cidx = blockIdx.x * 2u + (threadIdx.x >> 5);
+    const uint32_t cidx = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;      // wavefronts of a workgroup are independent
     const uint32_t l = threadIdx.x & 15u;
     const bool isZ = (threadIdx.x & 16u) != 0;
     uint32_t *mine = isZ ? Z : X;

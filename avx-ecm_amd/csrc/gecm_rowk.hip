@@ -5,8 +5,17 @@
 #include "gecm_row.hpp"
 #include <hip/hip_runtime.h>
 
+// Four wavefronts per workgroup (they do not interact).  With one, the first launch of a process was 41 % slower than
+// every later one in 13 of 18 runs (381 ms against 270 ms at 4096 curves, B1 = 1e5; 3.8 s against 2.7 s at B1 = 1e6 in
+// the command-line driver, whose only stage-1 launch is its first): these kernels need few registers, a SIMD can take
+// eight of their wavefronts, and nothing makes a cold dispatcher spread 2048 one-wavefront workgroups two per SIMD.
+// A workgroup of four puts one wavefront on each SIMD of a CU: 14 first launches of 14 at full speed
+// (profiles/r02_first_launch_workgroup_size.txt).
+#ifndef GECM_ROW_WG_WAVES
+#define GECM_ROW_WG_WAVES 4
+#endif
 template <int NQ, int ROWS, bool ALDS>
-__global__ void __launch_bounds__(64, 2)
+__global__ void __launch_bounds__(64 * GECM_ROW_WG_WAVES, 2)
 k_stage1_row(const uint32_t *__restrict__ tape, uint32_t tape_len, uint32_t *__restrict__ X, uint32_t *__restrict__ Z,
              const uint32_t *__restrict__ S, size_t stride, uint32_t nl, const uint32_t *__restrict__ rc, uint32_t rho_n)
 {
@@ -21,7 +30,7 @@ extern "C" int gecm_launch_stage1_row(void *stream, int nq, int rows, const uint
                                       uint32_t *Z, const uint32_t *S, size_t stride, uint32_t nl, const uint32_t *rc,
                                       uint32_t rho_n, int a_lds)
 {
-    const dim3 grid((unsigned)(stride / 2)), block(64);
+    const dim3 grid((unsigned)(stride / (2 * GECM_ROW_WG_WAVES))), block(64 * GECM_ROW_WG_WAVES);   // stride: a multiple of 64
 #define GECM_ROW_LAUNCH(q, r)                                                                                               \
     if (nq == q && rows == r) {                                                                                             \
         if (a_lds)                                                                                                          \
