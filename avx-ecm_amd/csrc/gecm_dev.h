@@ -80,7 +80,7 @@ uint32_t gecm_dev_s2_fail_planes(gecm_dev *d);
 /* ecm_stage2_pair for one range: steps = nsteps words pairs: (0xffffffff, n) = generate the next n
  * giant steps (n <= G), else (ring slot, table index).  G = chunk size, ring_size = power of two. */
 int gecm_dev_s2_pair(gecm_dev *d, const uint32_t *steps, uint32_t nsteps, uint32_t D, uint32_t G,
-                     uint32_t ring_size, uint64_t A0);
+                     uint32_t ring_size, uint64_t A0, uint64_t tape_id);
 #define GECM_S2_BLK 256   /* baby-step normalisation block (= S2_BLK in gecm_stage2.hpp) */
 /* canonical Montgomery-form accumulator and the failed-inversion gcd records ([limb][curve]) */
 int gecm_dev_s2_download(gecm_dev *d, uint32_t *acc, uint32_t *fail);

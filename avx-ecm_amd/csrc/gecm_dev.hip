@@ -51,6 +51,8 @@ struct gecm_dev {
     uint32_t *dPa = nullptr, *dSteps = nullptr, *dFlags = nullptr;
     size_t flags_cap = 0;
     size_t s2_npb = 0, s2_G = 0, s2_ring = 0, s2_stride = 0, steps_cap = 0, keep_cap = 0;
+    uint64_t steps_id = 0;    // the kept tape whose copy dSteps holds (0: none), and its length
+    uint32_t steps_n = 0;
     uint32_t s2_slices = 1;   // stage-2 accumulators per curve (pair-walk slices), see gecm_dev_s2_init
     uint32_t s2_K = 1;        // sub-sequences per curve for the table build and the giant steps (gecm_dev_s2_subseq)
     uint32_t *dKBlk = nullptr, *dKPa = nullptr, *dPdK = nullptr, *dTgt = nullptr;
@@ -570,7 +572,7 @@ extern "C" int gecm_dev_s2_init(gecm_dev *d, const uint32_t *keep, size_t keep_w
 }
 
 extern "C" int gecm_dev_s2_pair(gecm_dev *d, const uint32_t *steps, uint32_t nsteps, uint32_t D, uint32_t G,
-                                uint32_t ring_size, uint64_t A0)
+                                uint32_t ring_size, uint64_t A0, uint64_t tape_id)
 {
     HIPCHK(hipSetDevice(d->device));
     if (!d->dPbX || d->s2_G != G || d->s2_ring != ring_size || (ring_size & (ring_size - 1))) {
@@ -582,10 +584,15 @@ extern "C" int gecm_dev_s2_pair(gecm_dev *d, const uint32_t *steps, uint32_t nst
     if (words > d->steps_cap) {
         (void)hipFree(d->dSteps);
         d->dSteps = nullptr;
+        d->steps_id = 0;
         HIPCHK(hipMalloc(&d->dSteps, words * 4));
         d->steps_cap = words;
     }
-    if (nsteps) HIPCHK(hipMemcpyAsync(d->dSteps, steps, (size_t)nsteps * 8, hipMemcpyHostToDevice, d->stream));
+    // tape_id != 0 names a tape the host keeps from batch to batch: the device copy of the last one is kept too
+    if (nsteps && !(tape_id && tape_id == d->steps_id && nsteps == d->steps_n))
+        HIPCHK(hipMemcpyAsync(d->dSteps, steps, (size_t)nsteps * 8, hipMemcpyHostToDevice, d->stream));
+    d->steps_id = tape_id;
+    d->steps_n = nsteps;
     gecm_s2_pair_args a;
     a.X = d->dX; a.Z = d->dZ; a.S = d->dS; a.PbX = d->dPbX; a.npb = (uint32_t)d->s2_npb;
     a.PdX = d->dPd; a.PdZ = d->dPd + coord / 4;

@@ -51,6 +51,19 @@ static uint64_t lcg_rand(uint64_t *state)
     return *state;
 }
 
+/* the pair map of the first prime range of stage 2 (ecm.c:1441-1443): identical for every batch, GPU and pass, so it
+ * is made once, on the main thread, while the GPUs run the first stage 1 */
+typedef struct {
+    uint64_t lo, hi;
+    uint32_t D, U;
+    gecm_pairs pm;
+    int valid, rc;
+    int settled;               /* made or failed: the job threads wait for this before they prepare their tapes */
+    pthread_mutex_t mu;
+    pthread_cond_t cv;
+} first_range_t;
+
+
 typedef struct {
     int gpu;
     gecm_ctx *ctx;
@@ -62,6 +75,7 @@ typedef struct {
     char err[512];
     double t_build, t_stage1, t_s2;
     const gecm_pairs *pm;      /* the pair map of the current prime range (made once, shared) */
+    first_range_t *fr;         /* stage 1: the first range's map, being made on the main thread meanwhile (or NULL) */
 } job_t;
 
 static void *job_build(void *p)
@@ -80,7 +94,17 @@ static void *job_stage1(void *p)
     double t = now();
     j->rc = 0;
     if (j->ncurves) {
-        j->rc = gecm_stage1(j->ctx, j->B1);
+        j->rc = gecm_stage1(j->ctx, j->B1);                           /* returns after the launch */
+        if (j->rc == 0 && j->fr) {
+            /* while the kernel runs: this context's launch tape of the first stage-2 range, as soon as the main
+             * thread has the pair map (0.13 s of host time; later passes find it kept) */
+            first_range_t *fr = j->fr;
+            pthread_mutex_lock(&fr->mu);
+            while (!fr->settled) pthread_cond_wait(&fr->cv, &fr->mu);
+            pthread_mutex_unlock(&fr->mu);
+            if (fr->valid)
+                (void)gecm_stage2_pair_prepare(j->ctx, fr->D, fr->U, fr->pm.steps, fr->pm.pairmap_v, fr->pm.pairmap_u, fr->pm.amin);
+        }
         if (j->rc == 0) j->rc = gecm_sync(j->ctx);
         if (j->rc < 0) snprintf(j->err, sizeof j->err, "%s", gecm_last_error());
     }
@@ -114,30 +138,28 @@ static void *job_stage2_pair(void *p)
     return NULL;
 }
 
-/* the pair map of the first prime range of stage 2 (ecm.c:1441-1443): identical for every batch, GPU and pass, so it
- * is made once, on the main thread, while the GPUs run the first stage 1 */
-typedef struct {
-    uint64_t lo, hi;
-    uint32_t D, U;
-    gecm_pairs pm;
-    int valid, rc;
-} first_range_t;
-
 static void make_first_range(first_range_t *fr)
 {
-    if (fr->valid) return;
-    fr->rc = gecm_pair_primes(&fr->pm, fr->lo, fr->hi, fr->D, fr->U);
-    fr->valid = fr->rc == 0;
+    if (!fr->valid) {
+        fr->rc = gecm_pair_primes(&fr->pm, fr->lo, fr->hi, fr->D, fr->U);
+        fr->valid = fr->rc == 0;
+    }
+    pthread_mutex_lock(&fr->mu);
+    fr->settled = 1;
+    pthread_cond_broadcast(&fr->cv);
+    pthread_mutex_unlock(&fr->mu);
 }
 
 static int run_all(job_t *jobs, int n, void *(*fn)(void *), first_range_t *meanwhile)
 {
     pthread_t th[MAX_GPUS];
     if (meanwhile) {                         /* every job on a thread of its own, the host work here */
+        for (int i = 0; i < n; i++) jobs[i].fr = meanwhile;
         for (int i = 0; i < n; i++) pthread_create(&th[i], NULL, fn, &jobs[i]);
         make_first_range(meanwhile);
         for (int i = 0; i < n; i++) pthread_join(th[i], NULL);
     } else {
+        for (int i = 0; i < n; i++) jobs[i].fr = NULL;
         for (int i = 1; i < n; i++) pthread_create(&th[i], NULL, fn, &jobs[i]);
         fn(&jobs[0]);
         for (int i = 1; i < n; i++) pthread_join(th[i], NULL);
@@ -225,6 +247,8 @@ int main(int argc, char **argv)
 
     first_range_t first_range;
     memset(&first_range, 0, sizeof first_range);
+    pthread_mutex_init(&first_range.mu, NULL);
+    pthread_cond_init(&first_range.cv, NULL);
     first_range.lo = B1;
     first_range.hi = B1 + 100000000ULL < B2 ? B1 + 100000000ULL : B2;
     first_range.D = gecm_s2_default_D(B1);

@@ -64,6 +64,12 @@ struct gecm_ctx {
     uint32_t fail_planes;    /* planes of hfail: 1, or 1 + sub-sequences (gecm_dev_s2_fail_planes) */
     gecm_pairs pm;           /* pair map of the last single-range gecm_stage2 call (pm_valid), reused while (range, D, U) match */
     int pm_valid;
+    gecm_s2_tape tp;         /* the device tape made from pm (tp_valid): it depends on (pm, D, U) only, so it is kept with it */
+    int tp_valid;
+    uint64_t tp_id;          /* identifies the kept tape to the device side, which then keeps its copy too */
+    gecm_s2_tape ptp;        /* the tape of the last gecm_stage2_pair call (ptp_valid), found again by a fingerprint of the map */
+    int ptp_valid;
+    uint64_t ptp_fp, ptp_id;
     uint64_t pm_lo, pm_hi;
     uint32_t pm_D, pm_U;
     int have_acc;
@@ -289,6 +295,21 @@ static void free_batch(gecm_ctx *c)
     c->have_plain = 0;
 }
 
+/* the kept pair map of a single-range stage 2 and the device tape made from it */
+static void drop_kept_pairmap(gecm_ctx *c)
+{
+    if (c->pm_valid) gecm_pairmap_release(&c->pm);
+    c->pm_valid = 0;
+    if (c->tp_valid) free(c->tp.words);
+    c->tp_valid = 0;
+}
+
+static uint64_t next_tape_id(void)
+{
+    static uint64_t next_id = 1;                     /* ids only tell tapes apart on the device side */
+    return __atomic_fetch_add(&next_id, 1, __ATOMIC_RELAXED);
+}
+
 void gecm_destroy(gecm_ctx *c)
 {
     if (!c) return;
@@ -299,7 +320,8 @@ void gecm_destroy(gecm_ctx *c)
     gecm_tape_free(&c->tape);
     free_batch(c);
     gecm_s2_plan_free(&c->s2);
-    if (c->pm_valid) gecm_pairmap_release(&c->pm);
+    drop_kept_pairmap(c);
+    if (c->ptp_valid) free(c->ptp.words);
     free(c->r3_28);
     free(c->n28);
     free(c);
@@ -980,33 +1002,102 @@ void gecm_pairmap_release(gecm_pairs *p)
     memset(p, 0, sizeof *p);
 }
 
-int gecm_stage2_pair(gecm_ctx *c, uint32_t steps, const uint32_t *pm_v, const uint32_t *pm_u, uint32_t amin)
+/* launch the giant steps and the pair walk of one range from a built tape; tape_id != 0: the device keeps its copy */
+static int s2_run_tape(gecm_ctx *c, const gecm_s2_tape *t, uint32_t amin, uint64_t tape_id)
 {
-    if (!c || !c->s2_ready) { set_err("gecm_stage2_pair: gecm_stage2_init has not run"); return GECM_ERR_STATE; }
-    if (steps && (!pm_v || !pm_u)) return GECM_ERR_ARG;
     const gecm_s2_plan *p = &c->s2;
-    gecm_s2_tape t;
-    uint32_t bad = 0;
-    int trc = gecm_s2_tape_build(&t, p, steps, pm_v, pm_u, amin, S2_GIANT_CHUNK, S2_RING, &bad);
-    if (trc == -1) return GECM_ERR_NOMEM;
-    if (trc) {                                                           /* ecm.c:2508-2517 */
-        set_err("gecm_stage2_pair: invalid pair map entry %u: (%u,%u)", bad, pm_v[bad], pm_u[bad]);
-        return GECM_ERR_ARG;
-    }
-    uint64_t A0 = (uint64_t)amin * p->D * 2;                             /* ecm.c:2378 */
-    t.adds += ladder_adds(A0) + ladder_adds(A0 - p->D);                  /* ecm.c:2383, 2390 */
-    int rc = gecm_dev_s2_pair(c->dev, t.words, (uint32_t)(t.nwords / 2), p->D, S2_GIANT_CHUNK, S2_RING, A0);
-    free(t.words);
+    const uint64_t A0 = (uint64_t)amin * p->D * 2;                       /* ecm.c:2378 */
+    int rc = gecm_dev_s2_pair(c->dev, t->words, (uint32_t)(t->nwords / 2), p->D, S2_GIANT_CHUNK, S2_RING, A0, tape_id);
     if (rc) { set_err("gecm_stage2_pair: %s", gecm_dev_error()); return GECM_ERR_DEVICE; }
-    c->s2_ptadds += t.adds; c->s2_numinv += t.inv; c->s2_paired += t.paired; c->s2_devinv += t.devinv;
-    c->s2_amin_last = t.amin_last;
+    c->s2_ptadds += t->adds + ladder_adds(A0) + ladder_adds(A0 - p->D);  /* ecm.c:2383, 2390 */
+    c->s2_numinv += t->inv; c->s2_paired += t->paired; c->s2_devinv += t->devinv;
+    c->s2_amin_last = t->amin_last;
     c->have_acc = 0;
     c->scan_valid[1] = 0;
     return GECM_OK;
 }
 
-/* The pair map of [B1, B2) depends on nothing the device computes: a caller can have it made while stage 1 runs
- * (gecm_stage1 returns after the launch).  Kept in the context; gecm_stage2 with the same (B2, D, U) finds it. */
+static int s2_build_tape(gecm_ctx *c, gecm_s2_tape *t, uint32_t steps, const uint32_t *pm_v, const uint32_t *pm_u, uint32_t amin)
+{
+    uint32_t bad = 0;
+    int trc = gecm_s2_tape_build(t, &c->s2, steps, pm_v, pm_u, amin, S2_GIANT_CHUNK, S2_RING, &bad);
+    if (trc == -1) return GECM_ERR_NOMEM;
+    if (trc) {                                                           /* ecm.c:2508-2517 */
+        set_err("gecm_stage2_pair: invalid pair map entry %u: (%u,%u)", bad, pm_v[bad], pm_u[bad]);
+        return GECM_ERR_ARG;
+    }
+    return GECM_OK;
+}
+
+/* FNV-1a over the pair map and what else the tape depends on */
+static uint64_t pairmap_fingerprint(uint32_t steps, const uint32_t *pm_v, const uint32_t *pm_u, uint32_t amin, uint32_t D, uint32_t U)
+{
+    uint64_t h = 1469598103934665603ull;
+    const uint32_t head[4] = {steps, amin, D, U};
+    for (int i = 0; i < 4; i++) h = (h ^ head[i]) * 1099511628211ull;
+    for (uint32_t i = 0; i < steps; i++) {
+        h = (h ^ pm_v[i]) * 1099511628211ull;
+        h = (h ^ pm_u[i]) * 1099511628211ull;
+    }
+    return h;
+}
+
+/* The tape of a pair map is the same for every batch and costs more host time than reading the map once (130 ms
+ * against 8 ms for the 3.0 M entries of a 1e8 range): the last one is kept and found again by a fingerprint of the map. */
+static int s2_tape_for(gecm_ctx *c, uint32_t steps, const uint32_t *pm_v, const uint32_t *pm_u, uint32_t amin)
+{
+    const uint64_t fp = pairmap_fingerprint(steps, pm_v, pm_u, amin, c->s2.D, c->s2.U);
+    if (c->ptp_valid && c->ptp_fp == fp) return GECM_OK;
+    if (c->ptp_valid) free(c->ptp.words);
+    c->ptp_valid = 0;
+    int rc = s2_build_tape(c, &c->ptp, steps, pm_v, pm_u, amin);
+    if (rc) return rc;
+    c->ptp_valid = 1;
+    c->ptp_fp = fp;
+    c->ptp_id = next_tape_id();
+    return GECM_OK;
+}
+
+int gecm_stage2_pair(gecm_ctx *c, uint32_t steps, const uint32_t *pm_v, const uint32_t *pm_u, uint32_t amin)
+{
+    if (!c || !c->s2_ready) { set_err("gecm_stage2_pair: gecm_stage2_init has not run"); return GECM_ERR_STATE; }
+    if (steps && (!pm_v || !pm_u)) return GECM_ERR_ARG;
+    int rc = s2_tape_for(c, steps, pm_v, pm_u, amin);
+    if (rc) return rc;
+    return s2_run_tape(c, &c->ptp, amin, c->ptp_id);
+}
+
+/* Optional, for callers of the phase functions: make (and keep) the tape gecm_stage2_pair will need for this pair map
+ * and (D, U) ahead of time — e.g. while the device runs stage 1.  Touches nothing on the device. */
+int gecm_stage2_pair_prepare(gecm_ctx *c, uint32_t D, uint32_t U, uint32_t steps, const uint32_t *pm_v, const uint32_t *pm_u,
+                             uint32_t amin)
+{
+    if (!c || (steps && (!pm_v || !pm_u))) return GECM_ERR_ARG;
+    if (!D || !U || U > (S2_RING - S2_GIANT_CHUNK) / 4) { set_err("gecm_stage2_pair_prepare: bad D/U"); return GECM_ERR_ARG; }
+    if (c->s2.D != D || c->s2.U != U) {                                  /* the plan gecm_stage2_init(D, U) would make */
+        gecm_s2_plan_free(&c->s2);
+        c->s2_ready = 0;
+        if (gecm_s2_plan_init(&c->s2, D, U)) { set_err("gecm_stage2_pair_prepare: bad D/U"); return GECM_ERR_ARG; }
+    }
+    return s2_tape_for(c, steps, pm_v, pm_u, amin);
+}
+
+/* keep `pm` (ownership passes to the context) and make the tape that goes with it; the plan of (D, U) must be c->s2 */
+static int keep_pairmap(gecm_ctx *c, gecm_pairs *pm, uint64_t lo, uint64_t hi)
+{
+    drop_kept_pairmap(c);
+    c->pm = *pm;
+    c->pm_valid = 1; c->pm_lo = lo; c->pm_hi = hi; c->pm_D = c->s2.D; c->pm_U = c->s2.U;
+    int rc = s2_build_tape(c, &c->tp, c->pm.steps, c->pm.pairmap_v, c->pm.pairmap_u, c->pm.amin);
+    if (rc) return rc;                                                   /* the map stays; the tape is made (and refused) again later */
+    c->tp_valid = 1;
+    c->tp_id = next_tape_id();
+    return GECM_OK;
+}
+
+/* The pair map of [B1, B2) and the device tape made from it depend on nothing the device computes: a caller can have
+ * them made while stage 1 runs (gecm_stage1 returns after the launch).  Kept in the context; gecm_stage2 with the same
+ * (B2, D, U) finds them, and the device keeps its copy of the tape from one batch to the next. */
 int gecm_stage2_prepare(gecm_ctx *c, uint64_t B2, uint32_t D, uint32_t U)
 {
     const uint64_t PRIME_RANGE = 100000000ull;
@@ -1014,14 +1105,17 @@ int gecm_stage2_prepare(gecm_ctx *c, uint64_t B2, uint32_t D, uint32_t U)
     if (!D) D = gecm_s2_default_D(c->B1);
     if (!U) U = GECM_S2_DEFAULT_U;
     if (B2 - c->B1 > PRIME_RANGE) return GECM_OK;                        /* several ranges: made range by range later */
+    if (U > (S2_RING - S2_GIANT_CHUNK) / 4) return GECM_OK;              /* gecm_stage2_init will refuse it */
     if (c->pm_valid && c->pm_lo == c->B1 && c->pm_hi == B2 && c->pm_D == D && c->pm_U == U) return GECM_OK;
+    if (c->s2.D != D || c->s2.U != U) {                                  /* the plan gecm_stage2_init(D, U) would make */
+        gecm_s2_plan_free(&c->s2);
+        c->s2_ready = 0;
+        if (gecm_s2_plan_init(&c->s2, D, U)) { set_err("gecm_stage2_prepare: bad D/U"); return GECM_ERR_ARG; }
+    }
     gecm_pairs pm;
     int rc = gecm_pair_primes(&pm, c->B1, B2, D, U);
     if (rc) return rc;
-    if (c->pm_valid) gecm_pairmap_release(&c->pm);
-    c->pm = pm;
-    c->pm_valid = 1; c->pm_lo = c->B1; c->pm_hi = B2; c->pm_D = D; c->pm_U = U;
-    return GECM_OK;
+    return keep_pairmap(c, &pm, c->B1, B2);
 }
 
 int gecm_stage2(gecm_ctx *c, uint64_t B2, uint32_t D, uint32_t U)
@@ -1033,10 +1127,24 @@ int gecm_stage2(gecm_ctx *c, uint64_t B2, uint32_t D, uint32_t U)
     for (uint64_t p = c->B1; p < B2; p += PRIME_RANGE) {                 /* ecm.c:1424-1476 */
         uint64_t hi = p + PRIME_RANGE < B2 ? p + PRIME_RANGE : B2;
         /* the pair map depends on (range, D, U) only: a run of many batches (the reference: one per 8 curves and
-         * thread) computes it once; the last single-range map is kept in the context */
+         * thread) computes it once; the last single-range map is kept in the context, with its tape */
         const int cacheable = (p == c->B1 && hi == B2);
-        if (cacheable && c->pm_valid && c->pm_lo == p && c->pm_hi == hi && c->pm_D == c->s2.D && c->pm_U == c->s2.U) {
-            rc = gecm_stage2_pair(c, c->pm.steps, c->pm.pairmap_v, c->pm.pairmap_u, c->pm.amin);
+        const int kept = c->pm_valid && c->pm_lo == p && c->pm_hi == hi && c->pm_D == c->s2.D && c->pm_U == c->s2.U;
+        if (cacheable && !kept) {
+            gecm_pairs pm;
+            rc = gecm_pair_primes(&pm, p, hi, c->s2.D, c->s2.U);
+            if (rc) return rc;
+            rc = keep_pairmap(c, &pm, p, hi);
+            if (rc) return rc;
+        }
+        if (cacheable) {
+            if (!c->tp_valid) {                                          /* a map kept without its tape: make it now */
+                gecm_pairs pm = c->pm;
+                c->pm_valid = 0;
+                rc = keep_pairmap(c, &pm, p, hi);
+                if (rc) return rc;
+            }
+            rc = s2_run_tape(c, &c->tp, c->pm.amin, c->tp_id);
             if (rc) return rc;
             continue;
         }
@@ -1044,13 +1152,7 @@ int gecm_stage2(gecm_ctx *c, uint64_t B2, uint32_t D, uint32_t U)
         rc = gecm_pair_primes(&pm, p, hi, c->s2.D, c->s2.U);
         if (rc) return rc;
         rc = gecm_stage2_pair(c, pm.steps, pm.pairmap_v, pm.pairmap_u, pm.amin);
-        if (cacheable && !rc) {
-            if (c->pm_valid) gecm_pairmap_release(&c->pm);
-            c->pm = pm;
-            c->pm_valid = 1; c->pm_lo = p; c->pm_hi = hi; c->pm_D = c->s2.D; c->pm_U = c->s2.U;
-        } else {
-            gecm_pairmap_release(&pm);
-        }
+        gecm_pairmap_release(&pm);
         if (rc) return rc;
     }
     return gecm_sync(c);

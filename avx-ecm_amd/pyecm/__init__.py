@@ -89,13 +89,15 @@ _sig("gecm_stage2_pair", c_int, c_void_p, ctypes.c_uint32, ctypes.POINTER(ctypes
      ctypes.POINTER(ctypes.c_uint32), ctypes.c_uint32)
 _sig("gecm_stage2", c_int, c_void_p, c_u64, ctypes.c_uint32, ctypes.c_uint32)
 _sig("gecm_stage2_prepare", c_int, c_void_p, c_u64, ctypes.c_uint32, ctypes.c_uint32)
+_sig("gecm_stage2_pair_prepare", c_int, c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
+     ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32), ctypes.c_uint32)
 _sig("gecm_get_stage2_stats", c_int, c_void_p, ctypes.POINTER(Stage2Stats))
 _sig("gecm_download_acc", c_int, c_void_p, c_void_p)
 _sig("gecm_stage2_factor", c_int, c_void_p, c_size_t, c_char_p, c_size_t, ctypes.POINTER(c_int))
 _sig("gecm_scan_factors", c_int, c_void_p, c_int, ctypes.POINTER(c_size_t))
 _sig("gecm_curve_flag", c_int, c_void_p, c_int, c_size_t)
 EXPORTS += ["gecm_scan_factors", "gecm_curve_flag", "gecm_prepare_input", "gecm_sizeinbase10"]
-EXPORTS += ["gecm_stage2_init", "gecm_pair_primes", "gecm_pairmap_release", "gecm_stage2_pair", "gecm_stage2", "gecm_stage2_prepare",
+EXPORTS += ["gecm_stage2_init", "gecm_pair_primes", "gecm_pairmap_release", "gecm_stage2_pair", "gecm_stage2", "gecm_stage2_prepare", "gecm_stage2_pair_prepare",
             "gecm_get_stage2_stats", "gecm_download_acc", "gecm_stage2_factor"]
 
 
@@ -291,6 +293,11 @@ class Engine:
         _chk(lib.gecm_stage2_pair(self._h, pairs.steps, pairs.pairmap_v, pairs.pairmap_u, pairs.amin), "gecm_stage2_pair")
         if sync:
             self.sync()
+
+    def stage2_pair_prepare(self, pairs, D, U):
+        """host side of stage2_pair(pairs) ahead of time (the launch tape of that pair map); no device work"""
+        _chk(lib.gecm_stage2_pair_prepare(self._h, D, U, pairs.steps, pairs.pairmap_v, pairs.pairmap_u, pairs.amin),
+             "gecm_stage2_pair_prepare")
 
     def stage2_stats(self):
         st = Stage2Stats()

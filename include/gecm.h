@@ -202,6 +202,12 @@ void gecm_pairmap_release(gecm_pairs *p);
  * reference (pairmap_steps, pairmap_v, pairmap_u, work->amin).  Asynchronous.                   */
 int gecm_stage2_pair(gecm_ctx *ctx, uint32_t steps, const uint32_t *pairmap_v, const uint32_t *pairmap_u,
                      uint32_t amin);
+/* Optional: the host-side preparation gecm_stage2_pair makes for a pair map (its launch tape) ahead of time, e.g.
+ * while the device runs stage 1; D, U as for gecm_stage2_init (explicit, not 0).  The reference has no counterpart
+ * (its ecm_stage2_pair walks the map directly, ecm.c:2448-2533).  gecm_stage2_pair keeps the tape of the last map it
+ * saw either way and recognises the map by a fingerprint, so a run of many batches prepares it once. */
+int gecm_stage2_pair_prepare(gecm_ctx *ctx, uint32_t D, uint32_t U, uint32_t steps, const uint32_t *pairmap_v,
+                             const uint32_t *pairmap_u, uint32_t amin);
 
 /* Convenience: the whole stage-2 sequence of vececm (ecm.c:1401-1476) for primes in [B1, B2):
  * init, then pair + stage2_pair per range of 1e8.  Synchronous.                                  */
