@@ -109,6 +109,52 @@ def test_stage2_phase_api_matches_convenience(orc):
     assert acc[0] == want[0][0] and acc[1] == want[1][0]
 
 
+def test_stage2_kept_tapes_are_found_again_and_never_mistaken(orc):
+    """The launch tape of a pair map is kept from batch to batch (gecm_stage2_pair: by a fingerprint of the map;
+    gecm_stage2: with the kept map; gecm_stage2_pair_prepare: ahead of time).  Same map again, another map, another
+    (D, U), and the convenience call in between: every accumulator is the oracle's."""
+    import pyecm
+    sig = list(range(900, 966))
+    b1 = 2500
+    eng = pyecm.Engine(K1N)
+
+    def fresh():
+        eng.build_curves(sig)
+        eng.stage1(b1)
+
+    def check(b2, D, U):
+        acc = eng.download_acc()
+        want = _oracle(orc, K1N, [sig[0], sig[65]], b1, b2, D, U)
+        assert acc[0] == want[0][0] and acc[65] == want[1][0], (b2, D, U)
+
+    fresh()
+    pm_a = pyecm.pair_primes(b1, 120000, 1155, 16)
+    eng.stage2_pair_prepare(pm_a, 1155, 16)               # before any stage-2 state exists on the device
+    eng.stage2_init(1155, 16)
+    eng.stage2_pair(pm_a)
+    check(120000, 1155, 16)
+    fresh()
+    eng.stage2_init(1155, 16)
+    eng.stage2_pair(pm_a)                                 # the same map: tape and device copy kept
+    check(120000, 1155, 16)
+    fresh()
+    pm_b = pyecm.pair_primes(b1, 90000, 1155, 16)         # another map of the same (D, U)
+    eng.stage2_init(1155, 16)
+    eng.stage2_pair(pm_b)
+    check(90000, 1155, 16)
+    fresh()
+    eng.stage2(120000, 385, 4)                            # the convenience call with another plan in between
+    check(120000, 385, 4)
+    fresh()
+    eng.stage2(120000, 385, 4)                            # ... and again: its own kept map and tape
+    check(120000, 385, 4)
+    fresh()
+    eng.stage2_init(1155, 16)
+    eng.stage2_pair(pm_a)                                 # back to the first map after the plan changed twice
+    check(120000, 1155, 16)
+    eng.close()
+
+
 def _kat(name, lanes=1):
     import pyecm
     case = S1[name]
