@@ -202,6 +202,12 @@ int main(int argc, char **argv)
     if (have < 1) { fprintf(stderr, "no HIP device visible\n"); return 2; }
     int gpus = have;
     if (getenv("GECM_GPUS") && atoi(getenv("GECM_GPUS")) > 0 && atoi(getenv("GECM_GPUS")) < gpus) gpus = atoi(getenv("GECM_GPUS"));
+    /* GECM_CONTEXTS_PER_GPU=k (rehearsal knob): k contexts, each with its host thread, on every device used — the
+     * multi-context path of this driver on a box with one GPU.  Nothing is gained by it. */
+    int per_gpu = 1;
+    if (getenv("GECM_CONTEXTS_PER_GPU") && atoi(getenv("GECM_CONTEXTS_PER_GPU")) > 1) per_gpu = atoi(getenv("GECM_CONTEXTS_PER_GPU"));
+    const int devices = gpus;
+    gpus *= per_gpu;
     if (gpus > MAX_GPUS) gpus = MAX_GPUS;
     if (numcurves == 0 || B1 < 2 || B1 > 100000000ULL) { printf("need curves >= 1 and 2 <= B1 <= 1e8\n"); return 1; }
     /* main.c:585-589: at least one curve per thread, the same number on every thread; ecm.c:1151: every thread
@@ -215,7 +221,7 @@ int main(int argc, char **argv)
     memset(jobs, 0, sizeof jobs);
     for (int g = 0; g < gpus; g++) {
         jobs[g].gpu = g;
-        if (gecm_create(&jobs[g].ctx, g, ndec, 52)) { fprintf(stderr, "%s\n", gecm_last_error()); return 2; }
+        if (gecm_create(&jobs[g].ctx, g % devices, ndec, 52)) { fprintf(stderr, "%s\n", gecm_last_error()); return 2; }
     }
     gecm_config cfg;
     gecm_get_config(jobs[0].ctx, &cfg);

@@ -118,3 +118,18 @@ def test_cli_two_gpus_write_the_same_files():
     assert one[1] == two[1] and len(one[1].splitlines()) == 64
     strip = lambda ls: [__import__("re").sub(r"thread \d+, vec \d+", "", l) for l in ls]
     assert strip(one[2]) == strip(two[2])
+
+
+@pytest.mark.parametrize("contexts", [2, 3])
+def test_cli_several_contexts_write_the_same_files(contexts):
+    """The same multi-context path on whatever the box has: GECM_CONTEXTS_PER_GPU puts several contexts, each with its
+    host thread, on one device (curves split between them, the first stage-2 range's pair map shared, every context's
+    tape prepared while its stage-1 kernel runs).  save_b1.txt and ecm_results.txt equal the one-context run's."""
+    c = S1["n415_b1_10000_b2_1e6"]
+    one = _run([c["N"], 72, c["B1"], 1, c["B2"], c["sigma0"]], env={"GECM_GPUS": "1"})
+    many = _run([c["N"], 72, c["B1"], 1, c["B2"], c["sigma0"]], env={"GECM_GPUS": "1", "GECM_CONTEXTS_PER_GPU": str(contexts)})
+    assert "%d GPU(s)" % contexts in many[0] and "1 GPU(s)" in one[0]
+    assert one[1] == many[1] and len(one[1].splitlines()) == 72
+    strip = lambda ls: [__import__("re").sub(r"thread \d+, vec \d+", "", l) for l in ls]
+    assert strip(one[2]) == strip(many[2])
+    assert one[1].splitlines()[:len(c["save_lines"])] == c["save_lines"]
