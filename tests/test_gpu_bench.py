@@ -38,3 +38,15 @@ def test_bench_as_a_rank_under_torch_distributed_run():
     d = _line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                "--master-port", "29541", "bench.py"] + ARGS)
     assert d["n_gpus"] == 1 and "RCCL" in d["config"]["parallelism"] and d["value"] > 0
+
+
+def test_bench_two_ranks_with_engines_on_one_gpu():
+    """`--gpus 2` from a plain process: the launcher starts two ranks; on a one-GPU box both engines sit on device 0
+    (the rank's device is LOCAL_RANK modulo the visible devices) and the collectives go over gloo — RCCL does not put
+    two ranks on one device.  The line counts both ranks' curves."""
+    d = _line([sys.executable, "bench.py", "--gpus", "2", "--backend", "gloo"] + ARGS[2:])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0
+    assert d["config"]["curves_per_gpu"] == 256
+    assert "gloo" in d["config"]["parallelism"]
+    one = _line([sys.executable, "bench.py"] + ARGS)
+    assert d["config"]["curves_with_factor_last_step"] >= 0 and one["n_gpus"] == 1
