@@ -280,7 +280,17 @@ extern "C" int gecm_dev_auto_lanes(gecm_dev *d)
      * curves on every SIMD of the chip twice: 1.8x the eight-lane layout at 4096 curves (415 and 831 bits), 1.3x
      * at 1023 bits, 1.05x at 8192 curves, slower from there on (tools/row_check.py).  Below 10 limbs the
      * 16 lanes of a row are mostly padding and the eight-lane layout wins. */
-    if (!d->fform && d->row_nq && d->nl >= 10 && d->stride && d->stride <= (size_t)d->cus * 32) return 32;
+    /* Above 8192 curves (measured at 15, 30 and 37 limbs, profiles/r02_layouts_mid_batches.txt): the 32-lane kernel's
+     * time grows with the batch, the eight- and two-lane kernels' in steps (one more wavefront per SIMD), so the
+     * 32-lane layout still wins where the others have just taken a step: one limb per lane (up to 15 limbs) up to 56
+     * curves per CU (18.7k against 16.2k curves/s at 12,288 curves, 415 bits; the two-lane layout takes over at
+     * 14.4k); more limbs per lane up to 30 curves per CU and from 32 to 50 (831 bits: 31.9k against 29.7k curves/s at
+     * 12,288), the eight-lane layout at exactly one or two wavefronts per SIMD in between (8192 curves: 32.7k against
+     * 30.6k). */
+    if (!d->fform && d->row_nq && d->nl >= 10 && d->stride) {
+        const size_t s = d->stride, cu = (size_t)d->cus;
+        if (d->row_nq == 1 ? s <= cu * 56 : (s <= cu * 30 || (s > cu * 32 && s <= cu * 50))) return 32;
+    }
     if (!d->fform && d->dModQ && d->stride && d->stride <= (size_t)d->cus * (d->nl >= 19 ? 64 : 32)) return 8;
     if (d->nl >= 26) return 2;
     const size_t full = (size_t)d->cus * 4 * 128;
