@@ -88,7 +88,8 @@ def test_stage1_save_lines_b1_1e6_32_lanes_per_curve(case):
 
 
 def test_lanes_per_curve_is_chosen_from_the_batch_size():
-    """auto mode: two lanes per curve unless the batch fills whole rounds of 2 wavefronts per SIMD (256 CUs)"""
+    """auto mode: 32 lanes per curve for small batches, then 8 or 2, one when the batch fills whole rounds of 2
+    wavefronts per SIMD (256 CUs); the lines do not depend on the layout"""
     import pyecm
     case = next(c for c in CASES if c["name"] == "K1N_two_full_batches_b1_500")
     eng = pyecm.Engine(_n_of(case), digitbits=52)
@@ -97,7 +98,11 @@ def test_lanes_per_curve_is_chosen_from_the_batch_size():
     eng.stage1(500)
     assert eng.lanes_per_curve() == 32                      # 16 curves: far below 32 curves per CU
     small = [l.rstrip("\n") for l in eng.save_lines()]
-    eng.build_curves(list(range(100, 100 + 12000)))       # more than 32 curves per CU, not more than 64: 8 lanes each
+    eng.build_curves(list(range(100, 100 + 12000)))       # 47 curves per CU: still 32 lanes (gecm_dev_auto_lanes)
+    eng.stage1(500)
+    assert eng.lanes_per_curve() == 32
+    assert [l.rstrip("\n") for l in eng.save_lines()[:16]] == small
+    eng.build_curves(list(range(100, 100 + 15000)))       # 59 curves per CU: past the 32-lane layout's range
     eng.stage1(500)
     assert eng.lanes_per_curve() == (8 if eng.cfg.dev_limbs >= 19 else 2)
     assert [l.rstrip("\n") for l in eng.save_lines()[:16]] == small
