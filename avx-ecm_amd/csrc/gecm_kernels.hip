@@ -115,13 +115,16 @@ k_stage1_pair_f(const uint32_t *__restrict__ tape, uint32_t tape_len, uint32_t *
 // Eight lanes per curve (gecm_quad.hpp).
 #define GECM_HAS_QUAD 1
 #if GECM_HAS_QUAD
+// 256-thread workgroups (four independent wavefronts): this kernel needs about 65 registers, and one-wavefront
+// workgroups of such a kernel are not spread evenly by a cold dispatcher — see gecm_rowk.hip; its first launch of a
+// process measured 745 ms against 483 ms at 8192 curves.
 template <int NL>
-__global__ void __launch_bounds__(64, 2)
+__global__ void __launch_bounds__(256, 2)
 k_stage1_quad(const uint32_t *__restrict__ tape, uint32_t tape_len, uint32_t *__restrict__ X,
               uint32_t *__restrict__ Z, const uint32_t *__restrict__ S, size_t stride, const uint32_t *__restrict__ modq,
               uint32_t rho)
 {
-    const uint32_t cidx = blockIdx.x * 8u + (threadIdx.x >> 3);
+    const uint32_t cidx = (blockIdx.x * blockDim.x + threadIdx.x) >> 3;
     const uint32_t l = threadIdx.x & 3u;
     const bool isZ = (threadIdx.x & 4u) != 0;
     uint32_t *mine = isZ ? Z : X;
@@ -366,7 +369,7 @@ extern "C" int CAT(gecm_launch_stage1_quad_, GECM_NL)(void *stream, const gecm_m
                                                       const uint32_t *S, size_t stride, const uint32_t *modq)
 {
 #if GECM_HAS_QUAD
-    hipLaunchKernelGGL(k_stage1_quad<GECM_NL>, dim3((unsigned)(stride / 8)), dim3(64), 0, (hipStream_t)stream, tape,
+    hipLaunchKernelGGL(k_stage1_quad<GECM_NL>, dim3((unsigned)(stride / 32)), dim3(256), 0, (hipStream_t)stream, tape,   // stride: a multiple of 64
                        tape_len, X, Z, S, stride, modq, mc->rho);
     hipLaunchKernelGGL(k_canon<GECM_NL>, dim3((unsigned)(stride / 64)), dim3(64), 0, (hipStream_t)stream, X, Z, stride,
                        make_args<GECM_NL>(mc));
