@@ -206,12 +206,18 @@ def gen_stage2_acc():
     succeeds, so the accumulator is a well-defined product), VECLEN curves on one thread."""
     k1n = int([l for l in open("/root/reference/test.csh").read().splitlines() if "7372562557" in l][0].split()[1])
     t35 = int(open("/root/reference/test_t35.csh").read().splitlines()[45].split()[1]) if os.path.exists("/root/reference/test_t35.csh") else k1n
+    M = lambda e: (1 << e) - 1
     cases = []
     for name, digitbits, n, b1, b2, sigma0 in (("K1N_b1_2000_b2_1e5", 52, k1n, 2000, 100000, 100),
                                                ("K1N_b1_5000_b2_3e5", 52, k1n, 5000, 300000, 200),
                                                ("K1N_b1_3000_b2_150000", 52, k1n, 3000, 150000, 500),
                                                ("T35N_b1_1000_b2_50000", 52, t35, 1000, 50000, 42),
-                                               ("K1N_d32_b1_300_b2_20000", 32, k1n, 300, 20000, 300)):
+                                               ("K1N_d32_b1_300_b2_20000", 32, k1n, 300, 20000, 300),
+                                               # the larger size classes: products of Mersenne primes (no small factors)
+                                               ("M607xM127xM89_b1_800_b2_40000", 52, M(607) * M(127) * M(89), 800, 40000, 700),
+                                               ("M607xM127xM107xM89xM61_d32_b1_500_b2_30000", 32,
+                                                M(607) * M(127) * M(107) * M(89) * M(61), 500, 30000, 900),
+                                               ("M521xM127_b1_1200_b2_60000", 52, M(521) * M(127), 1200, 60000, 1100)):
         print("stage2acc:", name, flush=True)
         exe = os.path.join(REFDIR, "avx-ecm-%d-tap" % digitbits)
         veclen = 8 if digitbits == 52 else 16
