@@ -1,6 +1,8 @@
 """Stage 2 at the bench's size: 131,072 curves, B2 = 1e8 on the device; the accumulators of sample lanes must equal
 the oracle's (oracle/ecm_oracle.c orc_stage2), and the factor flags must match gcd(acc, N) on the host.
-usage: python tools/full_size_stage2_check.py [B1] [B2] [curves]"""
+usage: python tools/full_size_stage2_check.py [B1] [B2] [curves] [modulus]
+modulus: K1 (default: the 412-bit K1 of the reference's tests) or a product of Mersenne primes "521x127", "607x127x89", ...
+for the other limb counts (no small factors)"""
 import ctypes, math, os, random, sys, time
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, os.path.join(ROOT, "avx-ecm_amd"))
@@ -11,8 +13,13 @@ curves = int(sys.argv[3]) if len(sys.argv) > 3 else 131072
 import json
 K1 = next(c for c in json.load(open(os.path.join(ROOT, "tests", "golden", "stage1.json"))) if c["name"] == "K1")
 n = int(K1["save_lines"][0].split("N=0x")[1].split(";")[0], 16)      # two large prime factors: accumulators are generic
+if len(sys.argv) > 4 and sys.argv[4] != "K1":
+    n = 1
+    for e in sys.argv[4].split("x"):
+        n *= (1 << int(e)) - 1
 sig = list(range(1000, 1000 + curves))
 eng = pyecm.Engine(n)
+print("modulus of %d bits, %d limbs on the device" % (n.bit_length(), eng.cfg.dev_limbs), flush=True)
 eng.build_curves(sig)
 eng.stage1(b1)
 t = time.time()
