@@ -19,6 +19,9 @@ typedef struct gecm_dev gecm_dev;
 enum { GECM_L0_MUL = 0, GECM_L0_SQR = 1, GECM_L0_ADD = 2, GECM_L0_SUB = 3, GECM_L0_ADDSUB = 4 };
 
 int gecm_dev_count(void);
+/* hashes of the sources the device objects were compiled from: "K:.. R:.. D:.." (Makefile; K = MIXED if the kernel
+ * objects disagree) */
+const char *gecm_dev_manifest(void);
 const char *gecm_dev_error(void);
 /* limb counts for which kernels are instantiated, ascending, 0-terminated */
 const int *gecm_dev_supported_nl(void);

@@ -2,6 +2,7 @@
 // dispatch to the per-limb-count kernel launchers of gecm_kernels.hip.
 #include "gecm_dev.h"
 #include "gecm_launch.h"
+#include "gecm_tape.h"
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include <cstdio>
@@ -44,6 +45,7 @@ struct gecm_dev {
     uint32_t *dX = nullptr, *dZ = nullptr, *dS = nullptr, *dT0 = nullptr, *dT1 = nullptr;
     uint32_t *dTape = nullptr;
     size_t tape_len = 0, tape_cap = 0;
+    std::vector<size_t> tape_cuts;   // byte offsets at which a stage-1 launch may start (gecm_dev_set_tape), first = 0, last = tape_len
     // stage 2
     std::vector<uint32_t> r3;
     uint32_t inv_iters = 0;
@@ -68,6 +70,36 @@ struct gecm_dev {
     int cus = 0;          // compute units of the device (4 SIMDs each)
     int last_lanes = 0;   // lanes per curve the last stage-1 launch used
 };
+
+// ---- source manifest (Makefile): "K:<hash of the kernel objects' sources, or MIXED> R:<rowk> D:<this file>"
+#ifndef GECM_MANIFEST
+#define GECM_MANIFEST "unset"
+#endif
+extern "C" const char *gecm_manifest_rowk(void);
+#define X(n) extern "C" const char *gecm_manifest_k_##n##_p1(void); extern "C" const char *gecm_manifest_k_##n##_p2(void);
+GECM_NL_LIST(X)
+#undef X
+extern "C" const char *gecm_dev_manifest(void)
+{
+    static std::string m;
+    if (m.empty()) {
+        std::string k;
+        bool mixed = false;
+#define X(n)                                                                       \
+        for (const char *h : {gecm_manifest_k_##n##_p1(), gecm_manifest_k_##n##_p2()}) { \
+            if (k.empty()) k = h;                                                  \
+            else if (k != h) mixed = true;                                         \
+        }
+        GECM_NL_LIST(X)
+#undef X
+        std::string t = std::string("K:") + (mixed ? "MIXED" : k) + " R:" + gecm_manifest_rowk() + " D:" + GECM_MANIFEST;
+#ifdef GECM_DEV_NL15
+        t += " DEV-BUILD(416-bit class only)";
+#endif
+        m = t;
+    }
+    return m.c_str();
+}
 
 extern "C" int gecm_dev_count(void)
 {
@@ -258,6 +290,23 @@ extern "C" int gecm_dev_set_tape(gecm_dev *d, const uint8_t *tape, size_t len)
     if (len) HIPCHK(hipMemcpyAsync(d->dTape, tape, len, hipMemcpyHostToDevice, d->stream));
     HIPCHK(hipStreamSynchronize(d->stream));
     d->tape_len = len;
+    /* A long tape (B1 in the 1e8s: 200 MB per prime range) runs as several launches.  Between two prac() calls only
+     * the point A is live (PRAC_BEGIN sets B = C = A, ecm.c:603-608), and that is what every stage-1 kernel stores at
+     * exit and loads at entry, so a launch may start at any PRAC_BEGIN byte — the 2-power doublings are such bytes
+     * too.  The kernels read the tape as words: cuts are taken at offsets that are multiples of 4.  GECM_TAPE_CHUNK
+     * (bytes) overrides the 16 MB default (tests cut short tapes with it). */
+    size_t chunk = (size_t)16 << 20;
+    if (const char *e = getenv("GECM_TAPE_CHUNK")) { long v = atol(e); if (v >= 4) chunk = (size_t)v; }
+    d->tape_cuts.clear();
+    d->tape_cuts.push_back(0);
+    for (size_t want = chunk; want < len; ) {
+        size_t off = (want + 3) & ~(size_t)3;
+        while (off < len && tape[off] != GECM_OP_PRAC_BEGIN) off += 4;
+        if (off >= len) break;
+        d->tape_cuts.push_back(off);
+        want = off + chunk;
+    }
+    d->tape_cuts.push_back(len);
     return 0;
 }
 
@@ -291,6 +340,10 @@ extern "C" int gecm_dev_auto_lanes(gecm_dev *d)
         const size_t s = d->stride, cu = (size_t)d->cus;
         if (d->row_nq == 1 ? s <= cu * 56 : (s <= cu * 30 || (s > cu * 32 && s <= cu * 50))) return 32;
     }
+    /* Below 10 limbs the 32-lane layout still has the shortest chain per curve (9 rows of 6 instructions): while the
+     * batch leaves it at one wavefront per SIMD or less (8 curves per CU) it is latency that counts — 8 curves of a
+     * 204-bit N at B1 = 3e6: 4.11 s against 7.15 s (eight lanes) and 8.42 s (two), tools/multirange_time.py. */
+    if (!d->fform && d->row_nq && d->nl < 10 && d->stride && d->stride <= (size_t)d->cus * 8) return 32;
     if (!d->fform && d->dModQ && d->stride && d->stride <= (size_t)d->cus * (d->nl >= 19 ? 64 : 32)) return 8;
     if (d->nl >= 26) return 2;
     const size_t full = (size_t)d->cus * 4 * 128;
@@ -344,11 +397,14 @@ extern "C" int gecm_dev_stage1(gecm_dev *d, int lanes_per_curve)
     d->last_lanes = lanes_per_curve;
     gecm_modconst mc = modconst(d);
     HIPCHK(hipEventRecord(d->ev0, d->stream));
+    for (size_t cut = 0; cut + 1 < d->tape_cuts.size(); cut++) {
+    const uint32_t *tp = d->dTape + d->tape_cuts[cut] / 4;
+    const uint32_t tl = (uint32_t)(d->tape_cuts[cut + 1] - d->tape_cuts[cut]);
     switch (d->nl) {
 #define X(n)                                                                                     \
     case n:                                                                                      \
         if (lanes_per_curve == 32) {                                                             \
-            if (gecm_launch_stage1_row(d->stream, d->row_nq, d->row_rows, d->dTape, (uint32_t)d->tape_len,    \
+            if (gecm_launch_stage1_row(d->stream, d->row_nq, d->row_rows, tp, tl,    \
                                        d->dX, d->dZ, d->dS, d->stride, (uint32_t)d->nl,          \
                                        d->dRowC, d->rho,                                 \
                                        row_a_lds(d))) {                                      \
@@ -357,19 +413,19 @@ extern "C" int gecm_dev_stage1(gecm_dev *d, int lanes_per_curve)
             }                                                                                    \
             gecm_launch_canon_##n(d->stream, &mc, d->dX, d->dZ, d->stride);                      \
         } else if (lanes_per_curve == 8) {                                                              \
-            if (gecm_launch_stage1_quad_##n(d->stream, &mc, d->dTape, (uint32_t)d->tape_len,     \
+            if (gecm_launch_stage1_quad_##n(d->stream, &mc, tp, tl,     \
                                             d->dX, d->dZ, d->dS, d->stride, d->dModQ)) {         \
                 g_err = "gecm_dev_stage1: no eight-lane kernel for this limb count";             \
                 return -2;                                                                       \
             }                                                                                    \
         } else if (d->fform)                                                                     \
-            gecm_launch_stage1_f_##n(d->stream, &mc, d->dTape, (uint32_t)d->tape_len, d->dX,     \
+            gecm_launch_stage1_f_##n(d->stream, &mc, tp, tl, d->dX,     \
                                      d->dZ, d->dS, d->stride, lanes_per_curve, d->fform);       \
         else if (lanes_per_curve == 2)                                                           \
-            gecm_launch_stage1_pair_##n(d->stream, &mc, d->dTape, (uint32_t)d->tape_len, d->dX,  \
+            gecm_launch_stage1_pair_##n(d->stream, &mc, tp, tl, d->dX,  \
                                         d->dZ, d->dS, d->stride);                                \
         else                                                                                     \
-            gecm_launch_stage1_##n(d->stream, &mc, d->dTape, (uint32_t)d->tape_len, d->dX,       \
+            gecm_launch_stage1_##n(d->stream, &mc, tp, tl, d->dX,       \
                                    d->dZ, d->dS, d->stride);                                     \
         break;
         GECM_NL_LIST(X)
@@ -377,6 +433,7 @@ extern "C" int gecm_dev_stage1(gecm_dev *d, int lanes_per_curve)
     default:
         g_err = "unsupported nl";
         return -2;
+    }
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(d->ev1, d->stream));

@@ -313,6 +313,12 @@ static S2Const<NL> make_s2(const gecm_modconst *mc)
 #define CAT_(a, b) a##b
 #define CAT(a, b) CAT_(a, b)
 
+// the hash of the sources this object was compiled from (Makefile: K_SHA); gecm_dev.hip collects them
+#ifndef GECM_MANIFEST
+#define GECM_MANIFEST "unset"
+#endif
+extern "C" const char *CAT(CAT(CAT(gecm_manifest_k_, GECM_NL), _p), GECM_PART)(void) { return GECM_MANIFEST; }
+
 #if GECM_HAS_PART(1)
 extern "C" void CAT(gecm_launch_stage1_, GECM_NL)(void *stream, const gecm_modconst *mc, const uint32_t *tape,
                                                    uint32_t tape_len, uint32_t *X, uint32_t *Z,

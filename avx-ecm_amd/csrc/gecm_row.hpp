@@ -356,7 +356,7 @@ __device__ __forceinline__ void run_tape_row(const uint32_t *__restrict__ tape, 
 }
 
 // Constants of the row kernel, one array of GECM_ROW_WORDS words per kind, limb j at word j (zero padded):
-//   [0] N' = m*N, = -1 mod 2^28      [1] N      [2] c_in = 2^28 * R' mod N (entry conversion)
+//   [0] N' = m*N, = -1 mod 2^28      [1] N      [2] c_in = R'^2 / R mod N (entry conversion: x R -> x R')
 //   [3] R mod N (exit conversion)    [4] K' of N (bias that makes the exit value's limbs non-negative)
 // (GECM_ROW_WORDS, GECM_ROW_KINDS: gecm_rowk.h)
 

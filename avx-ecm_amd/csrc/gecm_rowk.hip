@@ -45,3 +45,9 @@ extern "C" int gecm_launch_stage1_row(void *stream, int nq, int rows, const uint
 #undef GECM_ROW_LAUNCH
     return -1;
 }
+
+// the hash of the sources this object was compiled from (Makefile: R_SHA)
+#ifndef GECM_MANIFEST
+#define GECM_MANIFEST "unset"
+#endif
+extern "C" const char *gecm_manifest_rowk(void) { return GECM_MANIFEST; }

@@ -13,8 +13,8 @@
 //
 // Differences from the reference that do not change any result (inverses mod N are unique and
 // the accumulator is a product in a commutative ring):
-//   * the per-lane host mpz_invert (ecm.c:1919-1950, 2054-2085) becomes a fixed-iteration binary
-//     inversion on the device (fe_invert); a non-invertible product records gcd(product, N) per
+//   * the per-lane host mpz_invert (ecm.c:1919-1950, 2054-2085) becomes a fixed-iteration inversion
+//     on the device (fe_invert: division steps in batches of 28); a non-invertible product records gcd(product, N) per
 //     curve instead of writing it into stg2acc (ecm.c:1927-1939);
 //   * the baby-step table is normalised in blocks of S2_BLK entries (one inversion per block)
 //     rather than in one 7.7k-entry pass, so only the normalised X of each entry is kept in HBM;
@@ -512,6 +512,10 @@ __device__ __forceinline__ void s2_init_k(const S2InitArgs &a, const S2Const<NL>
     pt_ladder(PK, (uint64_t)K, s4, m);
     pt_sumdiff(sK, dK, PK, m);
     const uint32_t j0 = r ? r : K;                  // first member
+    // a failing inversion goes to plane 1 + r of the record, as in giant_chunk_k: the K sub-sequences of a curve are
+    // K wavefronts, and two of them failing with different gcds must not write the same limbs (plane 0 belongs to
+    // the single-chain inversions)
+    uint32_t *const failp = a.fail + (size_t)(1 + r) * NL * stride;
     const uint32_t toff = __builtin_amdgcn_readfirstlane(a.tgt_off[r]);
     uint32_t nblk = 0, e0 = toff;
     uint32_t mi = 0;
@@ -534,7 +538,7 @@ __device__ __forceinline__ void s2_init_k(const S2InitArgs &a, const S2Const<NL>
             tb_store(a.kbz, S2_BLK, sidx, nblk, T.Z);
             nblk++;
             if (nblk == S2_BLK) {
-                block_normalise<NL>(a.PbX, a.npb, e0, a.kbx, a.kbz, a.kbp, nblk, k, a.fail, stride, idx, a.tgt, sidx);
+                block_normalise<NL>(a.PbX, a.npb, e0, a.kbx, a.kbz, a.kbp, nblk, k, failp, stride, idx, a.tgt, sidx);
                 e0 += nblk;
                 nblk = 0;
             }
@@ -542,7 +546,7 @@ __device__ __forceinline__ void s2_init_k(const S2InitArgs &a, const S2Const<NL>
         p2 = p1;
         p1 = T;
     }
-    if (nblk) block_normalise<NL>(a.PbX, a.npb, e0, a.kbx, a.kbz, a.kbp, nblk, k, a.fail, stride, idx, a.tgt, sidx);
+    if (nblk) block_normalise<NL>(a.PbX, a.npb, e0, a.kbx, a.kbz, a.kbp, nblk, k, failp, stride, idx, a.tgt, sidx);
     if (r == 0) {
         Pt<NL> Pd = Q;
         pt_ladder(Pd, (uint64_t)a.D, s4, m);        // Pd = [w]Q   ecm.c:2332-2334

@@ -261,3 +261,8 @@ int calc_lite(mpl_t *out, const char *s)
     if (p.err || *p.s) return -1;
     return 0;
 }
+
+/* the hash of the host sources this object was compiled from (Makefile: H_SHA); gecm_version() compares them */
+#ifdef GECM_MANIFEST_FN
+const char *GECM_MANIFEST_FN(void) { return GECM_MANIFEST; }
+#endif

@@ -232,3 +232,8 @@ int gecm_sizeinbase10(const char *dec)
     if (!dec || mpl_set_str(&v, dec)) return GECM_ERR_ARG;
     return mpl_sizeinbase10(&v);
 }
+
+/* the hash of the host sources this object was compiled from (Makefile: H_SHA); gecm_version() compares them */
+#ifdef GECM_MANIFEST_FN
+const char *GECM_MANIFEST_FN(void) { return GECM_MANIFEST; }
+#endif

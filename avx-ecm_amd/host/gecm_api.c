@@ -20,6 +20,11 @@
 #include <unistd.h>
 
 #define LIMB_BITS 28
+/* largest B1: the 32-bit offsets of a range's tape and uint32 range indices are nowhere near it; the cap is the
+ * reference's own (its prime sieve serves ranges below 10^13 or so; ecm.c keeps primes in 64 bits) kept at a size one
+ * can still test */
+#define GECM_B1_MAX 1000000000000ull
+#define gecm_stage1_ranges_u(b1) gecm_stage1_ranges_plan(b1)
 
 static __thread char g_err[512];
 static void set_err(const char *fmt, ...)
@@ -30,7 +35,29 @@ static void set_err(const char *fmt, ...)
     va_end(ap);
 }
 const char *gecm_last_error(void) { return g_err; }
-const char *gecm_version(void) { return "libgecm 0.1 (gfx950)"; }
+/* "libgecm 0.3 (gfx950) K:<hash> R:<hash> D:<hash> H:<hash>": the hashes of the sources the objects inside this
+ * library were compiled from (avx-ecm_amd/Makefile: kernels, 32-lane kernels, device layer, host C), MIXED where
+ * objects of one group disagree.  tests/test_abi_cpu.py and __graft_entry__.smoke() recompute them from the tree. */
+#ifndef GECM_MANIFEST
+#define GECM_MANIFEST "unset"
+#endif
+const char *gecm_manifest_host_gecm_plan(void);
+const char *gecm_manifest_host_gecm_pair(void);
+const char *gecm_manifest_host_mpl(void);
+const char *gecm_manifest_host_calc_lite(void);
+const char *gecm_manifest_host_cunningham(void);
+const char *gecm_version(void)
+{
+    static char v[256];
+    if (!v[0]) {
+        const char *h[5] = {gecm_manifest_host_gecm_plan(), gecm_manifest_host_gecm_pair(), gecm_manifest_host_mpl(),
+                            gecm_manifest_host_calc_lite(), gecm_manifest_host_cunningham()};
+        int mixed = 0;
+        for (int i = 0; i < 5; i++) mixed |= strcmp(h[i], GECM_MANIFEST) != 0;
+        snprintf(v, sizeof v, "libgecm 0.3 (gfx950) %s H:%s", gecm_dev_manifest(), mixed ? "MIXED" : GECM_MANIFEST);
+    }
+    return v;
+}
 int gecm_device_count(void) { return gecm_dev_count(); }
 
 struct gecm_ctx {
@@ -51,11 +78,21 @@ struct gecm_ctx {
     uint32_t *hx, *hz;   /* last downloaded plain x, z: [nl][batch] */
     int have_plain;
     uint64_t B1;
-    /* tape cache */
+    /* tape cache: the tape of (tape_B1, tape_range), one ecm_stage1 call of the reference */
     gecm_tape_t tape;
     uint64_t tape_B1;
+    uint32_t tape_range;
     int tape_on_dev;
     double last_ms;
+    /* counters of the stage 1 in progress: summed over the ranges run since range 0 (work->ptadds / ptdups are
+     * cleared when the curves are built, ecm.c:1177-1178, and grow through every ecm_stage1 call) */
+    uint64_t s1_ptadds, s1_ptdups, s1_last_prime, s1_tape_len;
+    /* the next range's tape, compiled by a helper thread while the device runs the current range */
+    pthread_t pf_thread;
+    int pf_active, pf_rc;
+    gecm_tape_t pf_tape;
+    uint64_t pf_B1;
+    uint32_t pf_range;
     /* stage 2 */
     uint32_t *r3_28;
     gecm_s2_plan s2;
@@ -69,7 +106,8 @@ struct gecm_ctx {
     uint64_t tp_id;          /* identifies the kept tape to the device side, which then keeps its copy too */
     gecm_s2_tape ptp;        /* the tape of the last gecm_stage2_pair call (ptp_valid), found again by a fingerprint of the map */
     int ptp_valid;
-    uint64_t ptp_fp, ptp_id;
+    uint64_t ptp_fp, ptp_fp2, ptp_id;
+    uint32_t ptp_steps, ptp_amin, ptp_D, ptp_U;
     uint64_t pm_lo, pm_hi;
     uint32_t pm_D, pm_U;
     int have_acc;
@@ -85,6 +123,7 @@ struct gecm_ctx {
     int ff_k, ff_sign, ff_nl, ff_on, ff_pending, ff_loaded, last_on_f;
     uint64_t ff_c;           /* Mw = 2^ff_k - ff_c for ff_sign > 0 (1: Mersenne form), 2^ff_k + 1 for ff_sign < 0 */
     uint64_t ff_tape_B1;
+    uint32_t ff_tape_range;
     mpl_t ff_M, ff_r_mod_m;  /* Mw; 2^(28 ff_nl) mod Mw */
     uint32_t *ff_n28;        /* n, kp, one for dev_f */
 };
@@ -317,6 +356,7 @@ void gecm_destroy(gecm_ctx *c)
     gecm_dev_close(c->dev_l0);
     gecm_dev_close(c->dev_f);
     free(c->ff_n28);
+    if (c->pf_active) { pthread_join(c->pf_thread, NULL); c->pf_active = 0; gecm_tape_free(&c->pf_tape); }
     gecm_tape_free(&c->tape);
     free_batch(c);
     gecm_s2_plan_free(&c->s2);
@@ -729,22 +769,70 @@ static int ff_settle(gecm_ctx *c)
 }
 
 /* ---- phase 1 -------------------------------------------------------------------------------- */
-int gecm_stage1(gecm_ctx *c, uint64_t B1)
+static void *prefetch_run(void *arg)
+{
+    gecm_ctx *c = (gecm_ctx *)arg;
+    c->pf_rc = gecm_tape_build_stage1_range(&c->pf_tape, c->pf_B1, c->pf_range, host_threads());
+    return NULL;
+}
+
+/* the tape of ecm_stage1's call number `range` for bound B1 into c->tape: kept from the last call, taken from the
+ * helper thread that compiled it while the device ran the range before, or compiled now */
+static int tape_for(gecm_ctx *c, uint64_t B1, uint32_t range)
+{
+    if (c->tape.ops && c->tape_B1 == B1 && c->tape_range == range) return GECM_OK;
+    int rc;
+    if (c->pf_active) {
+        pthread_join(c->pf_thread, NULL);
+        c->pf_active = 0;
+        if (!c->pf_rc && c->pf_B1 == B1 && c->pf_range == range) {
+            gecm_tape_free(&c->tape);
+            c->tape = c->pf_tape;
+            memset(&c->pf_tape, 0, sizeof c->pf_tape);
+            c->tape_B1 = B1; c->tape_range = range; c->tape_on_dev = 0;
+            return GECM_OK;
+        }
+        gecm_tape_free(&c->pf_tape);
+    }
+    gecm_tape_free(&c->tape);
+    rc = gecm_tape_build_stage1_range(&c->tape, B1, range, host_threads());
+    if (rc) { set_err("gecm_stage1: tape build failed (%d)", rc); return rc == -1 ? GECM_ERR_NOMEM : GECM_ERR_STATE; }
+    c->tape_B1 = B1; c->tape_range = range; c->tape_on_dev = 0;
+    return GECM_OK;
+}
+
+int gecm_stage1_ranges(uint64_t B1) { return (int)gecm_stage1_ranges_u(B1); }
+
+int gecm_stage1_describe_range(uint64_t B1, uint64_t B2, uint32_t range, gecm_stage1_range_desc *out)
+{
+    gecm_range_info ri;
+    if (!out || B1 < 2 || B1 > GECM_B1_MAX) { set_err("gecm_stage1_describe_range: bad argument"); return GECM_ERR_ARG; }
+    int rc = gecm_stage1_range_info(&ri, B1, B2, range);
+    if (rc) { set_err("gecm_stage1_describe_range: %s", rc == -1 ? "out of memory" : "no such range"); return rc == -1 ? GECM_ERR_NOMEM : GECM_ERR_ARG; }
+    out->lo = ri.lo; out->hi = ri.hi; out->nprimes = ri.nprimes; out->first_prime = ri.first_prime;
+    out->last_prime = ri.last_prime; out->checkpoint = ri.exhausted;
+    return GECM_OK;
+}
+
+int gecm_stage1_range(gecm_ctx *c, uint64_t B1, uint32_t range)
 {
     if (c && c->ff_pending) { int rcs = ff_settle(c); if (rcs) return rcs; }
     if (!c || c->batch == 0) { set_err("gecm_stage1: no curves uploaded"); return GECM_ERR_STATE; }
-    if (B1 < 2 || B1 > 100000000ull) { set_err("gecm_stage1: B1 must be in [2, 1e8]"); return GECM_ERR_ARG; }
-    if (c->tape_B1 != B1 || !c->tape.ops) {
-        gecm_tape_free(&c->tape);
-        int rc = gecm_tape_build_stage1(&c->tape, B1);
-        if (rc) { set_err("gecm_stage1: tape build failed (%d)", rc); return rc == -1 ? GECM_ERR_NOMEM : GECM_ERR_STATE; }
-        c->tape_B1 = B1;
-        c->tape_on_dev = 0;
-    }
+    if (B1 < 2 || B1 > GECM_B1_MAX) { set_err("gecm_stage1: B1 must be in [2, %llu]", (unsigned long long)GECM_B1_MAX); return GECM_ERR_ARG; }
+    const uint32_t nranges = gecm_stage1_ranges_u(B1);
+    if (range >= nranges) { set_err("gecm_stage1_range: B1 = %llu has %u prime range(s)", (unsigned long long)B1, nranges); return GECM_ERR_ARG; }
+    int rc = tape_for(c, B1, range);
+    if (rc) return rc;
     if (!c->tape_on_dev) {
+        /* stream-ordered after the kernel of the range before; returns when the copy is done */
         if (gecm_dev_set_tape(c->dev, c->tape.ops, c->tape.len)) { set_err("%s", gecm_dev_error()); return GECM_ERR_DEVICE; }
         c->tape_on_dev = 1;
     }
+    if (range == 0) c->s1_ptadds = c->s1_ptdups = 0;
+    c->s1_ptadds += c->tape.ptadds;
+    c->s1_ptdups += c->tape.ptdups;
+    c->s1_last_prime = c->tape.last_prime;
+    c->s1_tape_len = c->tape.len;
     c->B1 = B1;
     c->have_plain = 0;
     c->have_acc = 0;
@@ -756,18 +844,37 @@ int gecm_stage1(gecm_ctx *c, uint64_t B1)
     const int small_batch = want == 8 || want == 32;
     if (c->dev_f && c->ff_on && c->ff_loaded && !small_batch) {
         /* N | 2^k - 1: run the chain modulo 2^k - 1 with the F-form multiply; ff_settle brings X, Z back */
-        if (c->ff_tape_B1 != B1) {
+        if (c->ff_tape_B1 != B1 || c->ff_tape_range != range) {
             if (gecm_dev_set_tape(c->dev_f, c->tape.ops, c->tape.len)) { set_err("%s", gecm_dev_error()); return GECM_ERR_DEVICE; }
             c->ff_tape_B1 = B1;
+            c->ff_tape_range = range;
         }
         if (gecm_dev_stage1(c->dev_f, c->lanes_per_curve)) { set_err("%s", gecm_dev_error()); return GECM_ERR_DEVICE; }
         c->ff_pending = 1;
         c->last_on_f = 1;
-        return GECM_OK;
+    } else {
+        c->last_on_f = 0;
+        c->ff_loaded = 0;       /* the F-form copy of the points no longer matches */
+        if (gecm_dev_stage1(c->dev, c->lanes_per_curve)) { set_err("%s", gecm_dev_error()); return GECM_ERR_DEVICE; }
     }
-    c->last_on_f = 0;
-    c->ff_loaded = 0;       /* the F-form copy of the points no longer matches */
-    if (gecm_dev_stage1(c->dev, c->lanes_per_curve)) { set_err("%s", gecm_dev_error()); return GECM_ERR_DEVICE; }
+    if (range + 1 < nranges && !c->pf_active) {
+        /* while the device runs this range: the next one's tape (2 s of host time per 1e8 primes on 8 threads) */
+        c->pf_B1 = B1;
+        c->pf_range = range + 1;
+        c->pf_rc = 0;
+        c->pf_active = pthread_create(&c->pf_thread, NULL, prefetch_run, c) == 0;
+    }
+    return GECM_OK;
+}
+
+int gecm_stage1(gecm_ctx *c, uint64_t B1)
+{
+    if (B1 < 2 || B1 > GECM_B1_MAX) { set_err("gecm_stage1: B1 must be in [2, %llu]", (unsigned long long)GECM_B1_MAX); return GECM_ERR_ARG; }
+    const uint32_t nranges = gecm_stage1_ranges_u(B1);
+    for (uint32_t r = 0; r < nranges; r++) {             /* ecm.c:1209-1234 */
+        int rc = gecm_stage1_range(c, B1, r);
+        if (rc) return rc;
+    }
     return GECM_OK;
 }
 
@@ -817,10 +924,10 @@ double gecm_last_kernel_ms(const gecm_ctx *c) { return c ? c->last_ms : 0.0; }
 int gecm_get_stage1_stats(const gecm_ctx *c, gecm_stage1_stats *st)
 {
     if (!c || !st || !c->tape.ops) return GECM_ERR_STATE;
-    st->ptadds = c->tape.ptadds;
-    st->ptdups = c->tape.ptdups;
-    st->last_prime = c->tape.last_prime;
-    st->tape_len = c->tape.len;
+    st->ptadds = c->s1_ptadds;
+    st->ptdups = c->s1_ptdups;
+    st->last_prime = c->s1_last_prime;
+    st->tape_len = c->s1_tape_len;
     return GECM_OK;
 }
 
@@ -871,6 +978,11 @@ int gecm_download_points_plain(gecm_ctx *c, void *x, void *z)
 
 int gecm_format_save_line(gecm_ctx *c, size_t k, char *buf, size_t buflen)
 {
+    return gecm_format_resume_line(c, k, c ? c->B1 : 0, buf, buflen);
+}
+
+int gecm_format_resume_line(gecm_ctx *c, size_t k, uint64_t b1_label, char *buf, size_t buflen)
+{
     if (!c || !buf || k >= c->batch) return GECM_ERR_ARG;
     int rc = fetch_plain(c);
     if (rc) return rc;
@@ -883,7 +995,7 @@ int gecm_format_save_line(gecm_ctx *c, size_t k, char *buf, size_t buflen)
     mpl_get_hex(hzs, &v);
     /* ecm.c:1372-1380 */
     int n = snprintf(buf, buflen, "METHOD=ECM; SIGMA=%llu; B1=%llu; N=0x%s; X=0x%s; Z=0x%s; PROGRAM=AVX-ECM;\n",
-                     (unsigned long long)c->sigma[k], (unsigned long long)c->B1, hn, hxs, hzs);
+                     (unsigned long long)c->sigma[k], (unsigned long long)b1_label, hn, hxs, hzs);
     if (n < 0 || (size_t)n >= buflen) { set_err("gecm_format_save_line: buffer too small"); return GECM_ERR_ARG; }
     return n;
 }
@@ -966,7 +1078,18 @@ int gecm_stage2_init(gecm_ctx *c, uint32_t D, uint32_t U)
         }
         toff[K] = n;
     }
-    const uint32_t planes_before = c->fail_planes;
+    /* the host copy of the failure planes is sized before the device is touched: after an allocation failure the
+     * context still has its old stage-2 state, untouched */
+    const uint32_t planes = K > 1 ? K + 1 : 1;
+    if (planes != c->fail_planes || !c->hfail) {
+        uint32_t *nf = (uint32_t *)calloc(c->batch * (size_t)c->nl * planes, 4);
+        if (!nf) { free(tgt); return GECM_ERR_NOMEM; }
+        free(c->hfail);
+        c->hfail = nf;
+        c->fail_planes = planes;
+        c->have_acc = 0;
+    }
+    c->s2_ready = 0;
     int drc = gecm_dev_s2_init(c->dev, c->s2.keep, c->s2.keep_words, c->s2.umax, D, c->s2.npb, S2_GIANT_CHUNK, S2_RING, tgt,
                                toff, K);
     free(tgt);
@@ -974,12 +1097,7 @@ int gecm_stage2_init(gecm_ctx *c, uint32_t D, uint32_t U)
         set_err("gecm_stage2_init: %s", gecm_dev_error());
         return GECM_ERR_DEVICE;
     }
-    c->fail_planes = gecm_dev_s2_fail_planes(c->dev);
-    if (c->fail_planes != planes_before || !c->hfail) {
-        free(c->hfail);
-        c->hfail = (uint32_t *)calloc(c->batch * (size_t)c->nl * c->fail_planes, 4);
-        if (!c->hfail) return GECM_ERR_NOMEM;
-    }
+    if (gecm_dev_s2_fail_planes(c->dev) != planes) { set_err("gecm_stage2_init: failure planes out of step"); return GECM_ERR_STATE; }
     c->s2_ready = 1;
     return GECM_OK;
 }
@@ -1029,31 +1147,39 @@ static int s2_build_tape(gecm_ctx *c, gecm_s2_tape *t, uint32_t steps, const uin
     return GECM_OK;
 }
 
-/* FNV-1a over the pair map and what else the tape depends on */
-static uint64_t pairmap_fingerprint(uint32_t steps, const uint32_t *pm_v, const uint32_t *pm_u, uint32_t amin, uint32_t D, uint32_t U)
+/* Two independent 64-bit hashes of the pair map (FNV-1a over the words; a multiply-rotate mix over the 64-bit
+ * pairs (v, u) with their position), 8 ms for the 3.0 M entries of a 1e8 range */
+static void pairmap_fingerprint(uint32_t steps, const uint32_t *pm_v, const uint32_t *pm_u, uint64_t *h1, uint64_t *h2)
 {
-    uint64_t h = 1469598103934665603ull;
-    const uint32_t head[4] = {steps, amin, D, U};
-    for (int i = 0; i < 4; i++) h = (h ^ head[i]) * 1099511628211ull;
+    uint64_t a = 1469598103934665603ull, b = 0x9E3779B97F4A7C15ull;
     for (uint32_t i = 0; i < steps; i++) {
-        h = (h ^ pm_v[i]) * 1099511628211ull;
-        h = (h ^ pm_u[i]) * 1099511628211ull;
+        a = (a ^ pm_v[i]) * 1099511628211ull;
+        a = (a ^ pm_u[i]) * 1099511628211ull;
+        uint64_t w = (((uint64_t)pm_v[i] << 32) | pm_u[i]) + (uint64_t)i * 0xD6E8FEB86659FD93ull;
+        w *= 0xBF58476D1CE4E5B9ull;
+        b = ((b << 27) | (b >> 37)) ^ w;
+        b *= 0x94D049BB133111EBull;
     }
-    return h;
+    *h1 = a;
+    *h2 = b;
 }
 
 /* The tape of a pair map is the same for every batch and costs more host time than reading the map once (130 ms
- * against 8 ms for the 3.0 M entries of a 1e8 range): the last one is kept and found again by a fingerprint of the map. */
+ * against 8 ms): the last one is kept and recognised by (steps, amin, D, U) and both hashes of the map. */
 static int s2_tape_for(gecm_ctx *c, uint32_t steps, const uint32_t *pm_v, const uint32_t *pm_u, uint32_t amin)
 {
-    const uint64_t fp = pairmap_fingerprint(steps, pm_v, pm_u, amin, c->s2.D, c->s2.U);
-    if (c->ptp_valid && c->ptp_fp == fp) return GECM_OK;
+    uint64_t fp, fp2;
+    pairmap_fingerprint(steps, pm_v, pm_u, &fp, &fp2);
+    if (c->ptp_valid && c->ptp_steps == steps && c->ptp_amin == amin && c->ptp_D == c->s2.D && c->ptp_U == c->s2.U &&
+        c->ptp_fp == fp && c->ptp_fp2 == fp2)
+        return GECM_OK;
     if (c->ptp_valid) free(c->ptp.words);
     c->ptp_valid = 0;
     int rc = s2_build_tape(c, &c->ptp, steps, pm_v, pm_u, amin);
     if (rc) return rc;
     c->ptp_valid = 1;
-    c->ptp_fp = fp;
+    c->ptp_fp = fp; c->ptp_fp2 = fp2;
+    c->ptp_steps = steps; c->ptp_amin = amin; c->ptp_D = c->s2.D; c->ptp_U = c->s2.U;
     c->ptp_id = next_tape_id();
     return GECM_OK;
 }
@@ -1177,21 +1303,27 @@ static int fetch_acc(gecm_ctx *c)
 }
 
 /* The failed-inversion record of curve k: plane 0 (the single-chain inversions; after gecm_stage2_pair the
- * reference's last batch of the range) if it holds one, else the gcd of N with the product of the sub-sequences'
- * records (a curve whose inversions fail only here and there). */
+ * reference's last batch of the range) if it holds one; else the record of the last sub-sequence that holds a proper
+ * divisor of N (the reference keeps the gcd of its last failing batch, ecm.c:1925-1939); the gcd of N with the
+ * product of the records only when no single one is proper.  Every record is passed through gcd(., N) before it is
+ * believed: what comes out divides N. */
 static void fail_record(gecm_ctx *c, size_t k, mpl_t *g)
 {
     const size_t plane = c->batch * (size_t)c->nl;
-    mpl_from_limbs32(g, c->hfail + k, c->batch, c->nl, LIMB_BITS);
-    if (!mpl_is_zero(g) || c->fail_planes <= 1) return;
-    mpl_t prod, t;
+    mpl_t t, prod, gp;
+    mpl_from_limbs32(&t, c->hfail + k, c->batch, c->nl, LIMB_BITS);
+    if (!mpl_is_zero(&t)) { mpl_gcd(g, &t, &c->N); return; }
+    mpl_set_u64(g, 0);
+    if (c->fail_planes <= 1) return;
     mpl_set_u64(&prod, 0);
-    for (uint32_t p = 1; p < c->fail_planes; p++) {
+    for (uint32_t p = c->fail_planes - 1; p >= 1; p--) {
         mpl_from_limbs32(&t, c->hfail + p * plane + k, c->batch, c->nl, LIMB_BITS);
         if (mpl_is_zero(&t)) continue;
+        mpl_gcd(&gp, &t, &c->N);
+        if (mpl_cmp_u64(&gp, 1) > 0 && mpl_cmp(&gp, &c->N) != 0) { *g = gp; return; }
         if (mpl_is_zero(&prod)) prod = t;
         else mpl_mulmod(&prod, &prod, &t, &c->N);
-        if (mpl_is_zero(&prod)) { prod = c->N; break; }       /* the product covers N: gcd = N, "no factor" */
+        if (mpl_is_zero(&prod)) prod = c->N;                  /* the product covers N */
     }
     if (!mpl_is_zero(&prod)) mpl_gcd(g, &prod, &c->N);
 }
@@ -1250,6 +1382,12 @@ int gecm_scan_factors(gecm_ctx *c, int stage, size_t *first)
     if (!*f || !*hg) return GECM_ERR_NOMEM;
     if (gecm_dev_gcd_scan(c->dev, stage - 1, *f, *hg)) { set_err("gecm_scan_factors: %s", gecm_dev_error()); return GECM_ERR_DEVICE; }
     size_t n = 0, lo = c->batch;
+    if (stage == 1) {
+        /* x, z come to the host with the scan: everything a caller does next (save lines, factors of the flagged
+         * curves) is then host work, off the device's queue */
+        int rc = fetch_plain(c);
+        if (rc) return rc;
+    }
     if (stage == 2) {
         /* a failed batch inversion also marks its curve (ecm.c:1927-1939) */
         int rc = fetch_acc(c);
@@ -1272,3 +1410,8 @@ int gecm_curve_flag(const gecm_ctx *c, int stage, size_t k)
     if (!c || (stage != 1 && stage != 2) || k >= c->batch || !c->flags[stage - 1]) return 0;
     return (int)c->flags[stage - 1][k];
 }
+
+/* the hash of the host sources this object was compiled from (Makefile: H_SHA); gecm_version() compares them */
+#ifdef GECM_MANIFEST_FN
+const char *GECM_MANIFEST_FN(void) { return GECM_MANIFEST; }
+#endif

@@ -264,3 +264,8 @@ int gecm_s2_tape_build(gecm_s2_tape *out, const gecm_s2_plan *p, uint32_t steps,
     out->adds = adds; out->inv = inv; out->paired = paired; out->devinv = devinv; out->amin_last = run_amin;
     return 0;
 }
+
+/* the hash of the host sources this object was compiled from (Makefile: H_SHA); gecm_version() compares them */
+#ifdef GECM_MANIFEST_FN
+const char *GECM_MANIFEST_FN(void) { return GECM_MANIFEST; }
+#endif

@@ -12,6 +12,7 @@
  */
 #include "gecm_plan.h"
 #include "../csrc/gecm_tape.h"
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -161,31 +162,145 @@ int gecm_tape_append_prac(gecm_tape_t *t, uint64_t c)
     return d == 1 ? 0 : -2;                              /* ecm.c:877-880 */
 }
 
-int gecm_tape_build_stage1(gecm_tape_t *t, uint64_t B1)
+/* ---- one prime range of stage 1 -------------------------------------------------------------
+ * vececm calls ecm_stage1 once per range of PRIME_RANGE = 1e8 (ecm.c:1209-1234) with PRIMES = the primes of
+ * [rangemin, rangemax]; every call (ecm.c:1806-1854)
+ *   - runs the 2-power doublings again: one per power of two below B1 (ecm.c:1815-1822), in EVERY range;
+ *   - starts at PRIMES[1]: the range's first prime is never processed (2 in the first range, where the doublings
+ *     stand for it; the first prime above a multiple of 1e8 in the later ones);
+ *   - processes prac(q) for the primes q < B1 of the range, repeated while q^k < B1.
+ * The first range alone is the whole of stage 1 for B1 <= 1e8.  The chains of different primes are independent, so
+ * the range's primes are cut into slices compiled by worker threads and the pieces joined in order. */
+static uint64_t g_prime_range = GECM_PRIME_RANGE;
+/* test hook: walk the multi-range path with short ranges (tests compare with the oracle run the same way) */
+void gecm_plan_set_prime_range_for_tests(uint64_t range) { g_prime_range = range ? range : GECM_PRIME_RANGE; }
+
+typedef struct {
+    const uint64_t *primes;
+    size_t lo, hi;
+    uint64_t B1;
+    gecm_tape_t t;
+    int rc;
+} tape_slice;
+
+static void *tape_slice_run(void *arg)
+{
+    tape_slice *s = (tape_slice *)arg;
+    memset(&s->t, 0, sizeof s->t);
+    s->rc = 0;
+    for (size_t k = s->lo; k < s->hi && !s->rc; k++) {  /* ecm.c:1824-1832 */
+        const uint64_t q = s->primes[k];
+        uint64_t c = 1;
+        do {
+            s->rc = gecm_tape_append_prac(&s->t, q);
+            c *= q;
+        } while (!s->rc && (c * q) < s->B1);
+    }
+    return NULL;
+}
+
+uint32_t gecm_stage1_ranges_plan(uint64_t B1)
+{
+    return B1 <= g_prime_range ? 1u : (uint32_t)((B1 + g_prime_range - 1) / g_prime_range);   /* ecm.c:1209 */
+}
+
+int gecm_tape_build_stage1_range(gecm_tape_t *t, uint64_t B1, uint32_t range, int threads)
 {
     memset(t, 0, sizeof *t);
+    if (range >= gecm_stage1_ranges_plan(B1)) return -2;
+    const uint64_t lo = (uint64_t)range * g_prime_range;
+    const uint64_t hi = lo + g_prime_range < B1 ? lo + g_prime_range : B1;
     uint64_t q = 2;
     while (q < B1) {                                    /* ecm.c:1815-1822 */
         if (tape_push(t, GECM_OP_PRAC_BEGIN)) return -1;
         t->ptdups++;
         q *= 2;
     }
-    if (B1 > 2) t->last_prime = 2;
     size_t np = 0;
-    uint64_t *primes = gecm_primes_range(0, B1, &np);
-    if (!primes) return -1;
-    for (size_t k = 1; k < np; k++) {                   /* ecm.c:1824-1832 */
-        uint64_t c = 1;
-        q = primes[k];
-        do {
-            int rc = gecm_tape_append_prac(t, q);
-            if (rc) { free(primes); return rc; }
-            c *= q;
-        } while ((c * q) < B1);
-        t->last_prime = q;
+    uint64_t *primes = gecm_primes_range(lo, hi, &np);
+    if (!primes) { gecm_tape_free(t); return -1; }
+    /* "Stage 1 completed at prime PRIMES[last_pid - 1]" (ecm.c:1849): the last prime below B1, or PRIMES[0] itself
+     * when the loop never ran */
+    if (np) t->last_prime = primes[np - 1];
+    else {
+        size_t n2 = 0;
+        uint64_t *nx = gecm_primes_range(lo, lo + 2000, &n2);     /* prime gaps here are far below 2000 */
+        if (nx && n2) t->last_prime = nx[0];
+        free(nx);
+    }
+    if (np > 1) {
+        int nt = threads < 1 ? 1 : threads > 64 ? 64 : threads;
+        if ((size_t)nt > (np - 1) / 4096 + 1) nt = (int)((np - 1) / 4096 + 1);
+        tape_slice sl[64];
+        pthread_t th[64];
+        for (int i = 0; i < nt; i++) {
+            sl[i].primes = primes; sl[i].B1 = B1;
+            sl[i].lo = 1 + (np - 1) * (size_t)i / (size_t)nt;
+            sl[i].hi = 1 + (np - 1) * (size_t)(i + 1) / (size_t)nt;
+        }
+        for (int i = 1; i < nt; i++)
+            if (pthread_create(&th[i], NULL, tape_slice_run, &sl[i])) { tape_slice_run(&sl[i]); th[i] = 0; }
+        tape_slice_run(&sl[0]);
+        int rc = 0;
+        size_t total = t->len;
+        for (int i = 0; i < nt; i++) {
+            if (i > 0 && th[i]) pthread_join(th[i], NULL);
+            if (sl[i].rc) rc = sl[i].rc;
+            total += sl[i].t.len;
+        }
+        uint8_t *all = rc ? NULL : (uint8_t *)realloc(t->ops, total + 8);
+        if (!all) {
+            for (int i = 0; i < nt; i++) free(sl[i].t.ops);
+            free(primes);
+            gecm_tape_free(t);
+            return rc ? rc : -1;
+        }
+        t->ops = all;
+        for (int i = 0; i < nt; i++) {
+            if (sl[i].t.len) memcpy(t->ops + t->len, sl[i].t.ops, sl[i].t.len);
+            t->len += sl[i].t.len;
+            t->ptadds += sl[i].t.ptadds; t->ptdups += sl[i].t.ptdups; t->prac_calls += sl[i].t.prac_calls;
+            t->swaps += sl[i].t.swaps;
+            for (int r = 0; r < 4; r++) t->rule_count[r] += sl[i].t.rule_count[r];
+            free(sl[i].t.ops);
+        }
+        memset(t->ops + t->len, 0, 8);
     }
     free(primes);
     if (!t->ops) { t->ops = (uint8_t *)calloc(8, 1); if (!t->ops) return -1; }
+    return 0;
+}
+
+int gecm_tape_build_stage1(gecm_tape_t *t, uint64_t B1)
+{
+    if (B1 > g_prime_range) { memset(t, 0, sizeof *t); return -2; }     /* several ranges: one tape each */
+    int rc = gecm_tape_build_stage1_range(t, B1, 0, 1);
+    if (!rc && B1 > 2 && !t->last_prime) t->last_prime = 2;
+    return rc;
+}
+
+/* What vececm prints and decides around one range (ecm.c:1215-1247): the sieved interval [rangemin, rangemax] with
+ * rangemax = min(B2 + 1000, rangemin + 1e8), its prime count and first prime, the last prime below B1, and whether
+ * the range ends before B1 — the reference then appends the batch to checkpoint.txt (it tests PRIMES[last_pid] <
+ * B1 with last_pid = NUM_P, one past the list: the allocation is 1.25x an estimate and freshly mapped, so the word
+ * read is 0 and the test holds whenever the list is exhausted, also for B1 in (99999989, 1e8] in a single range). */
+int gecm_stage1_range_info(gecm_range_info *ri, uint64_t B1, uint64_t B2, uint32_t range)
+{
+    memset(ri, 0, sizeof *ri);
+    if (range >= gecm_stage1_ranges_plan(B1)) return -2;
+    if (B2 < B1) B2 = B1;
+    ri->lo = (uint64_t)range * g_prime_range;
+    ri->hi = B2 + 1000 < ri->lo + g_prime_range ? B2 + 1000 : ri->lo + g_prime_range;
+    size_t np = 0;
+    uint64_t *pr = gecm_primes_range(ri->lo, ri->hi + 1, &np);
+    if (!pr) return -1;
+    ri->nprimes = np;
+    ri->first_prime = np ? pr[0] : 0;
+    size_t i = 1;
+    while (i < np && pr[i] < B1) i++;                    /* ecm.c:1824: last_pid */
+    ri->last_prime = np ? pr[i - 1] : 0;
+    ri->exhausted = (i >= np);
+    free(pr);
     return 0;
 }
 
@@ -194,3 +309,8 @@ void gecm_tape_free(gecm_tape_t *t)
     free(t->ops);
     memset(t, 0, sizeof *t);
 }
+
+/* the hash of the host sources this object was compiled from (Makefile: H_SHA); gecm_version() compares them */
+#ifdef GECM_MANIFEST_FN
+const char *GECM_MANIFEST_FN(void) { return GECM_MANIFEST; }
+#endif

@@ -454,3 +454,8 @@ int mpl_sizeinbase10(const mpl_t *a)
     const unsigned __int128 p = (unsigned __int128)(0x4d104d427de7fbccULL + 1) * (unsigned)mpl_bits(a);
     return (int)(uint64_t)(p >> 64) + 1;
 }
+
+/* the hash of the host sources this object was compiled from (Makefile: H_SHA); gecm_version() compares them */
+#ifdef GECM_MANIFEST_FN
+const char *GECM_MANIFEST_FN(void) { return GECM_MANIFEST; }
+#endif

@@ -94,6 +94,16 @@ _sig("gecm_stage2_pair_prepare", c_int, c_void_p, ctypes.c_uint32, ctypes.c_uint
 _sig("gecm_get_stage2_stats", c_int, c_void_p, ctypes.POINTER(Stage2Stats))
 _sig("gecm_download_acc", c_int, c_void_p, c_void_p)
 _sig("gecm_stage2_factor", c_int, c_void_p, c_size_t, c_char_p, c_size_t, ctypes.POINTER(c_int))
+class RangeDesc(ctypes.Structure):
+    _fields_ = [("lo", c_u64), ("hi", c_u64), ("nprimes", c_u64), ("first_prime", c_u64), ("last_prime", c_u64),
+                ("checkpoint", c_int)]
+
+
+_sig("gecm_stage1_ranges", c_int, c_u64)
+_sig("gecm_stage1_range", c_int, c_void_p, c_u64, ctypes.c_uint32)
+_sig("gecm_stage1_describe_range", c_int, c_u64, c_u64, ctypes.c_uint32, ctypes.POINTER(RangeDesc))
+_sig("gecm_format_resume_line", c_int, c_void_p, c_size_t, c_u64, c_char_p, c_size_t)
+EXPORTS += ["gecm_stage1_ranges", "gecm_stage1_range", "gecm_stage1_describe_range", "gecm_format_resume_line"]
 _sig("gecm_scan_factors", c_int, c_void_p, c_int, ctypes.POINTER(c_size_t))
 _sig("gecm_curve_flag", c_int, c_void_p, c_int, c_size_t)
 EXPORTS += ["gecm_scan_factors", "gecm_curve_flag", "gecm_prepare_input", "gecm_sizeinbase10"]
@@ -119,6 +129,16 @@ def pair_primes(b1, b2, D, U):
 
 def device_count():
     return lib.gecm_device_count()
+
+
+def stage1_ranges(b1):
+    return lib.gecm_stage1_ranges(b1)
+
+
+def describe_range(b1, b2, r):
+    d = RangeDesc()
+    _chk(lib.gecm_stage1_describe_range(b1, b2, r, ctypes.byref(d)), "gecm_stage1_describe_range")
+    return d
 
 
 class Engine:
@@ -208,6 +228,17 @@ class Engine:
         _chk(lib.gecm_stage1(self._h, b1), "gecm_stage1")
         if sync:
             self.sync()
+
+    def stage1_range(self, b1, r, sync=True):
+        """one ecm_stage1 call of the reference's loop over prime ranges of 1e8 (ecm.c:1209-1234)"""
+        _chk(lib.gecm_stage1_range(self._h, b1, r), "gecm_stage1_range")
+        if sync:
+            self.sync()
+
+    def resume_line(self, k, b1_field):
+        buf = ctypes.create_string_buffer(8192)
+        _chk(lib.gecm_format_resume_line(self._h, k, b1_field, buf, len(buf)), "gecm_format_resume_line")
+        return buf.value.decode()
 
     def sync(self):
         _chk(lib.gecm_sync(self._h), "gecm_sync")

@@ -114,9 +114,31 @@ int gecm_sizeinbase10(const char *dec);
 
 /* ---- L1 phase 1: stage 1 (ecm_stage1, ecm.c:1806-1854) -------------------------------------
  * P <- [prod of prime powers < B1] P for every curve of the batch.  Asynchronous: returns after
- * the launch; gecm_sync waits.  B1 <= 10^8 (one prime range, ecm.c:1209-1234).                */
+ * the (last) launch; gecm_sync waits.  For B1 > 10^8 this is the whole loop of ecm.c:1209-1234:
+ * gecm_stage1_range for range 0, 1, ... in turn.                                               */
 int gecm_stage1(gecm_ctx *ctx, uint64_t B1);
 int gecm_sync(gecm_ctx *ctx);
+/* Stage 1 above one prime range.  vececm re-sieves every PRIME_RANGE = 10^8 and calls ecm_stage1 once per range
+ * (ecm.c:1209-1234); between the calls it appends the batch to checkpoint.txt (ecm.c:1236-1312).  One
+ * gecm_stage1_range call is one of those ecm_stage1 calls, with the reference's behaviour there reproduced so that
+ * the residues stay bit-identical: every call runs the 2-power doublings again (ecm.c:1815-1822) and starts at the
+ * SECOND prime of its range (ecm.c:1824: i = 1; the first prime above each multiple of 10^8 is never processed).
+ * range = 0 .. gecm_stage1_ranges(B1) - 1, in order, on the points the previous range left on the device;
+ * asynchronous like gecm_stage1.  While the device runs range r the library compiles the tape of range r + 1 on a
+ * helper thread.  B1 <= 10^12. */
+int gecm_stage1_ranges(uint64_t B1);                   /* ceil(B1 / 10^8), at least 1 */
+int gecm_stage1_range(gecm_ctx *ctx, uint64_t B1, uint32_t range);
+/* What vececm prints and decides around one range (ecm.c:1215-1247, 1849): the sieved interval [lo, hi] with
+ * hi = min(B2 + 1000, lo + 10^8) and its prime count ("Found %lu primes in range [lo : hi]"), P_MIN ("Commencing
+ * Stage 1 @ prime"), the last prime the call processes ("Stage 1 completed at prime", the B1 field of the
+ * checkpoint lines), and whether the reference writes checkpoint.txt after this range: it does when the range
+ * holds no prime >= B1 (ecm.c:1237 reads PRIMES[last_pid] one past the list, a zero word of the fresh
+ * allocation) — every range but the last, and also the last (or only) one when B1 lies above its last prime.   */
+typedef struct {
+    uint64_t lo, hi, nprimes, first_prime, last_prime;
+    int checkpoint;
+} gecm_stage1_range_desc;
+int gecm_stage1_describe_range(uint64_t B1, uint64_t B2, uint32_t range, gecm_stage1_range_desc *out);
 /* How stage 1 maps curves to lanes.  1 = one curve per lane (64 per wavefront): the throughput layout,
  * full speed from 2 wavefronts per SIMD, i.e. 128 x (4 x CUs) = 131072 curves on MI355X.  2 = the X and
  * the Z coordinate of a curve on two adjacent lanes (32 curves per wavefront): each point operation's
@@ -147,9 +169,9 @@ int gecm_get_lanes_per_curve(const gecm_ctx *ctx);
 double gecm_last_kernel_ms(const gecm_ctx *ctx);
 
 typedef struct {
-    uint64_t ptadds, ptdups;   /* ecm.c:441, 455; printed at ecm.c:1849-1850 */
-    uint64_t last_prime;       /* ecm.c:1849 */
-    uint64_t tape_len;
+    uint64_t ptadds, ptdups;   /* ecm.c:441, 455; printed at ecm.c:1849-1850: summed over the ranges run so far */
+    uint64_t last_prime;       /* ecm.c:1849: of the last range run */
+    uint64_t tape_len;         /* of the last range run */
 } gecm_stage1_stats;
 int gecm_get_stage1_stats(const gecm_ctx *ctx, gecm_stage1_stats *st);
 
@@ -163,6 +185,9 @@ int gecm_download_points_plain(gecm_ctx *ctx, void *x, void *z);
  *   "METHOD=ECM; SIGMA=%lu; B1=%lu; N=0x%Zx; X=0x%Zx; Z=0x%Zx; PROGRAM=AVX-ECM;\n"
  * from the last downloaded stage-1 result.  Returns the line length, or < 0.                  */
 int gecm_format_save_line(gecm_ctx *ctx, size_t k, char *buf, size_t buflen);
+/* The same line with another B1 field: the checkpoint.txt lines of ecm.c:1295-1305 carry the last prime of the
+ * range just finished (PRIMES[last_pid - 1]) instead of B1.                                              */
+int gecm_format_resume_line(gecm_ctx *ctx, size_t k, uint64_t b1_field, char *buf, size_t buflen);
 /* gcd(Z_k, N) after stage 1 (ecm.c:1336-1344): returns 1 and the factor as a decimal string if
  * 1 < g < N, else 0 (g == N is "no factor", ecm.c:2549-2553).                                 */
 int gecm_stage1_factor(gecm_ctx *ctx, size_t k, char *dec, size_t declen, int *is_prp);
@@ -205,7 +230,10 @@ int gecm_stage2_pair(gecm_ctx *ctx, uint32_t steps, const uint32_t *pairmap_v, c
 /* Optional: the host-side preparation gecm_stage2_pair makes for a pair map (its launch tape) ahead of time, e.g.
  * while the device runs stage 1; D, U as for gecm_stage2_init (explicit, not 0).  The reference has no counterpart
  * (its ecm_stage2_pair walks the map directly, ecm.c:2448-2533).  gecm_stage2_pair keeps the tape of the last map it
- * saw either way and recognises the map by a fingerprint, so a run of many batches prepares it once. */
+ * saw either way and recognises the map (its length, amin, D, U and two independent hashes of its words), so a run of
+ * many batches prepares it once.  Called with a (D, U) other than the one of the last gecm_stage2_init it replaces the
+ * context's stage-2 plan: results of a finished stage 2 (accumulator, factors) must have been read before.  The same
+ * holds for gecm_stage2_prepare below. */
 int gecm_stage2_pair_prepare(gecm_ctx *ctx, uint32_t D, uint32_t U, uint32_t steps, const uint32_t *pairmap_v,
                              const uint32_t *pairmap_u, uint32_t amin);
 

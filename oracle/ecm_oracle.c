@@ -544,6 +544,61 @@ int orc_stage1_line(orc_ctx *c, uint64_t sigma, uint64_t B1, char *line, size_t 
     return n;
 }
 
+/* vececm's loop over prime ranges for one sigma (ecm.c:1209-1234): ecm_stage1 is called once per range of
+ * `prime_range` (PRIME_RANGE = 1e8 in the reference, main.c:581; smaller values let tests walk the same path
+ * cheaply) with PRIMES = the primes of [rangemin, rangemax], rangemax = min(B2 + 1000, rangemin + prime_range)
+ * (ecm.c:1215-1216).  Every call repeats the 2-power doublings and starts at PRIMES[1] (orc_stage1 above).
+ * Stops after `stop_after` calls (0 = all of them).  The resume line carries b1_field, or — b1_field = 0 — the last
+ * prime processed, PRIMES[last_pid - 1], as the checkpoint lines of ecm.c:1295-1305 do (the final save line: pass B1).
+ * *checkpoint (if not NULL) = 1 when the reference would write checkpoint.txt after the last call made: it tests
+ * PRIMES[last_pid] < B1 (ecm.c:1237) where last_pid is one past the list if the range ran out — a zero word of the
+ * freshly mapped allocation. */
+int orc_stage1_ranges_line(orc_ctx *c, uint64_t sigma, uint64_t B1, uint64_t B2, uint64_t prime_range, int stop_after,
+                           uint64_t b1_field, char *line, size_t linelen, char *factor_dec, size_t faclen,
+                           uint64_t *counts, int *checkpoint)
+{
+    orc_work *w = work_new();
+    orc_pt P;
+    memset(&P, 0, sizeof P);
+    orc_build_curve(c, sigma, &P, w->s);
+    if (B2 < B1) B2 = B1;
+    uint64_t last_prime = 0;
+    int calls = 0, ckpt = 0;
+    for (uint64_t p = 0; p < B1; p += prime_range) {    /* ecm.c:1209 */
+        const uint64_t rangemax = B2 + 1000 < p + prime_range ? B2 + 1000 : p + prime_range;
+        size_t np;
+        uint64_t *primes = orc_primes(p, rangemax + 1, &np);
+        orc_stage1(c, w, &P, B1, primes, np);
+        size_t i = 1;
+        while (i < np && primes[i] < B1) i++;           /* work->last_pid, ecm.c:1844 */
+        last_prime = np ? primes[i - 1] : 0;
+        ckpt = i >= np;
+        free(primes);
+        if (++calls == stop_after) break;
+    }
+    if (counts) { counts[0] = w->ptadds; counts[1] = w->ptdups; counts[2] = last_prime; }
+    if (checkpoint) *checkpoint = ckpt;
+    fe_t one, x, z;
+    memset(one, 0, sizeof one);
+    one[0] = 1;
+    orc_mulmod(c, P.X, one, x);
+    orc_mulmod(c, P.Z, one, z);
+    mpz_t f, mx, mz;
+    mpz_inits(f, mx, mz, NULL);
+    int found = orc_check_factor(c, P.Z, f);
+    if (factor_dec && faclen) {
+        factor_dec[0] = 0;
+        if (found) gmp_snprintf(factor_dec, faclen, "%Zd", f);
+    }
+    fe_to_mpz(c, mx, x);
+    fe_to_mpz(c, mz, z);
+    int n = gmp_snprintf(line, linelen, "METHOD=ECM; SIGMA=%lu; B1=%lu; N=0x%Zx; X=0x%Zx; Z=0x%Zx; PROGRAM=AVX-ECM;\n",
+                         (unsigned long)sigma, (unsigned long)(b1_field ? b1_field : last_prime), c->N, mx, mz);
+    mpz_clears(f, mx, mz, NULL);
+    work_free(w);
+    return n;
+}
+
 double orc_time_stage1(orc_ctx *c, uint64_t sigma0, int curves, uint64_t B1)
 {
     size_t np;

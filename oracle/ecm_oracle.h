@@ -36,6 +36,14 @@ int orc_l0_hex(orc_ctx *c, int op, const char *a_hex, const char *b_hex, char *o
 int orc_stage1_line(orc_ctx *c, uint64_t sigma, uint64_t B1, char *line, size_t linelen, char *factor_dec,
                     size_t faclen, uint64_t *counts);
 
+/* The same through vececm's loop over prime ranges (ecm.c:1209-1312; B1 above prime_range = 1e8 in the reference):
+ * ecm_stage1 once per range, stopping after `stop_after` calls (0 = all).  b1_field = 0 writes the last prime
+ * processed into the line's B1 field, as the checkpoint.txt lines do (ecm.c:1295-1305).  counts[0..2] = point adds,
+ * doublings, last prime.  *checkpoint = the reference appends checkpoint.txt after the last call made. */
+int orc_stage1_ranges_line(orc_ctx *c, uint64_t sigma, uint64_t B1, uint64_t B2, uint64_t prime_range, int stop_after,
+                           uint64_t b1_field, char *line, size_t linelen, char *factor_dec, size_t faclen,
+                           uint64_t *counts, int *checkpoint);
+
 /* Stage 1 then stage 2 (ecm_stage2_init ecm.c:2201-2340, pair ecm.c:2559-2910, ecm_stage2_pair
  * ecm.c:2342-2540, driver loop ecm.c:1401-1476) for one sigma with explicit D and U (the reference
  * picks U through an uninitialised variable, main.c:912, 943; observed value 16).

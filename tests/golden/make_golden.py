@@ -17,7 +17,16 @@ into oracle/_ref/).  The fixtures are data (inputs + outputs); no reference sour
                 extract_bignum_from_vec_to_mpz; `make -C oracle reftap`), plus the D the reference chose
                 (main.c:838-872) and its stage-2 counters
 
-usage: python tests/golden/make_golden.py [--only stage1|l0|inputs|stage2acc] [--quick]
+  multirange.json : B1 > 1e8 (several prime ranges, ecm.c:1209-1312): checkpoint.txt, save_b1.txt, the factor
+                lines and the stdout lines of the reference for a 204-bit N at B1 = 1.1e8 (3 minutes of
+                reference time per case)
+
+  batches.json : runs of more than one reference batch (8 x threads curves, ecm.c:1151, 1531-1532): what the
+                reference writes when a batch finds a factor (it stops after that batch) and how it labels
+                curve / thread / vec with more than one thread (ecm.c:1356-1366; with a fixed sigma every
+                thread runs the same eight sigmas, ecm.c:1187)
+
+usage: python tests/golden/make_golden.py [--only stage1|l0|inputs|stage2acc|multirange|batches] [--quick]
 """
 import json, os, random, re, subprocess, sys, tempfile, hashlib
 
@@ -44,7 +53,7 @@ def test_csh_case(sigma):
 
 
 
-def run_ref(digitbits, n_expr, curves, b1, b2, sigma, threads=1):
+def run_ref(digitbits, n_expr, curves, b1, b2, sigma, threads=1, keep_stdout=False):
     exe = os.path.join(REFDIR, "avx-ecm-%d" % digitbits)
     with tempfile.TemporaryDirectory() as d:
         cmd = [exe, str(n_expr), str(curves), str(b1), str(threads), str(b2), str(sigma)]
@@ -53,6 +62,9 @@ def run_ref(digitbits, n_expr, curves, b1, b2, sigma, threads=1):
         save = []
         if os.path.exists(os.path.join(d, "save_b1.txt")):
             save = open(os.path.join(d, "save_b1.txt")).read().splitlines()
+        ckpt = None
+        if os.path.exists(os.path.join(d, "checkpoint.txt")):
+            ckpt = open(os.path.join(d, "checkpoint.txt")).read().splitlines()
         res = []
         if os.path.exists(os.path.join(d, "ecm_results.txt")):
             res = [l for l in open(os.path.join(d, "ecm_results.txt")).read().splitlines() if l.strip()]
@@ -68,7 +80,19 @@ def run_ref(digitbits, n_expr, curves, b1, b2, sigma, threads=1):
         "stage1_seconds_container": float(t1.group(1)) if t1 else None,
         "save_lines": save, "results_lines": res,
         "save_sha256": hashlib.sha256(("\n".join(save) + "\n").encode()).hexdigest() if save else None,
+        **({"checkpoint_lines": ckpt} if ckpt is not None else {}),
+        **({"stdout_lines": stdout_protocol(out)} if keep_stdout else {}),
     }
+
+
+def stdout_protocol(out):
+    """the reference's stdout without what changes from run to run: progress lines (\\r), pid, timings"""
+    keep = []
+    for l in out.replace("\r", "\n").splitlines():
+        if l.startswith(("accumulating prime", "starting process")) or re.search(r"took [0-9.]+ seconds", l):
+            continue
+        keep.append(l)
+    return keep
 
 
 def gen_stage1(quick):
@@ -242,6 +266,85 @@ def gen_stage2_acc():
     json.dump(cases, open(os.path.join(HERE, "stage2_acc.json"), "w"), indent=1)
 
 
+def semiprime_204():
+    """a 98-bit prime times a 106-bit prime (NWORDS = 4: the cheapest class), no small factors"""
+    def isprime(n):
+        if n < 2:
+            return False
+        for p in (2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37):
+            if n % p == 0:
+                return n == p
+        d, s = n - 1, 0
+        while d % 2 == 0:
+            d //= 2
+            s += 1
+        for a in (2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37):
+            x = pow(a, d, n)
+            if x in (1, n - 1):
+                continue
+            for _ in range(s - 1):
+                x = x * x % n
+                if x == n - 1:
+                    break
+            else:
+                return False
+        return True
+
+    def nextprime(n):
+        n |= 1
+        while not isprime(n):
+            n += 2
+        return n
+    r = random.Random(20261004)
+    p = nextprime(r.getrandbits(98) | 1 << 97)
+    q = nextprime(r.getrandbits(106) | 1 << 105)
+    return p * q
+
+
+def gen_multirange():
+    """B1 above one prime range: the reference re-sieves per range of 1e8, runs ecm_stage1 once per range and appends
+    a checkpoint.txt line per curve after every range but the last (ecm.c:1209-1312)."""
+    n = semiprime_204()
+    path = os.path.join(HERE, "multirange.json")
+    cases = json.load(open(path)) if os.path.exists(path) and "--keep" in sys.argv else []
+    have = {c["name"] for c in cases}
+    for name, b1, b2, sigma0 in (("n204_b1_1.1e8", 110000000, 110000000, 1000),
+                                 ("n204_b1_1.1e8_b2_1.3e8", 110000000, 130000000, 2000),
+                                 # one range whose primes all lie below B1: the reference writes a checkpoint even so
+                                 # (ecm.c:1237 reads one past its prime list)
+                                 ("n204_b1_1e8_single_range_checkpoint", 100000000, 100000000, 3000)):
+        if name in have:
+            continue
+        print("multirange:", name, flush=True)
+        c = run_ref(52, n, 8, b1, b2, sigma0, keep_stdout=True)
+        c["name"] = name
+        cases.append(c)
+    json.dump(cases, open(path, "w"), indent=1)
+
+
+def gen_batches():
+    """More curves than one reference batch (8 x threads)."""
+    n415 = rand_n(415)
+    k1n = int([l for l in open("/root/reference/test.csh").read().splitlines() if "7372562557" in l][0].split()[1])
+    cases = []
+    for name, n, curves, b1, b2, sigma0, threads in (
+            # small factors: the first batch finds one, the reference writes 8 lines and stops (ecm.c:1531-1532)
+            ("n415_64_curves_stops_after_first_batch", n415, 64, 1000, 1000, 1000, 1),
+            # two threads: batches of 16 lines, both threads on the same eight sigmas (ecm.c:1187), thread/vec labels
+            ("n415_64_curves_2_threads", n415, 64, 1000, 1000, 1000, 2),
+            # no factor anywhere: every batch is written
+            ("K1N_32_curves_2_threads_b1_300", k1n, 32, 300, 300, 100, 2),
+            ("K1N_40_curves_3_threads_b1_300", k1n, 40, 300, 300, 100, 3),
+            # a factor in the second batch only, found in stage 2 (lane 3 of batch 1)
+            ("n415_stage2_24_curves", n415, 24, 2000, 100000, 1000, 1)):
+        print("batches:", name, flush=True)
+        c = run_ref(52, n, curves, b1, b2, sigma0, threads=threads, keep_stdout=True)
+        c["name"] = name
+        c["threads"] = threads
+        cases.append(c)
+    json.dump(cases, open(os.path.join(HERE, "batches.json"), "w"), indent=1)
+
+
 if __name__ == "__main__":
     only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else None
     quick = "--quick" in sys.argv
@@ -253,3 +356,7 @@ if __name__ == "__main__":
         gen_inputs()
     if only in (None, "stage2acc"):
         gen_stage2_acc()
+    if only in (None, "multirange"):
+        gen_multirange()
+    if only in (None, "batches"):
+        gen_batches()

@@ -313,3 +313,83 @@ def test_pair_walk_kernels_with_hand_placed_loads_keep_their_rows_in_registers()
                 assert scratch == 0 and spills == 0, (nl, name, scratch, spills)
                 assert vgpr <= 256
     assert seen >= 10
+
+
+# ---- stage 1 above one prime range (ecm.c:1209-1312) ----
+MULTI = json.load(open(os.path.join(GOLDEN, "multirange.json"))) if os.path.exists(os.path.join(GOLDEN, "multirange.json")) else []
+
+
+@pytest.mark.skipif(not MULTI, reason="tests/golden/multirange.json not generated")
+def test_range_tapes_and_range_descriptions_match_the_reference_s_stdout(lib):
+    """per prime range: the counters after each ecm_stage1 call ("Stage 1 completed at prime p with a point-adds and
+    d point-doubles", cumulative: the doublings run again in every range), the sieved interval and its prime count
+    ("Found n primes in range [lo : hi]"), P_MIN, and whether a checkpoint follows — all from the reference's own
+    output for B1 = 1.1e8 and for B1 = 1e8 (one range, checkpoint written all the same)"""
+    import re
+    import pyecm
+    lib.gecm_tape_build_stage1_range.argtypes = [ctypes.POINTER(Tape), ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int]
+    for c in MULTI:
+        out = c["stdout_lines"]
+        found = [tuple(map(int, m.groups())) for m in (re.match(r"Found (\d+) primes in range \[(\d+) : (\d+)\]", l) for l in out) if m]
+        pmin = [int(m.group(1)) for m in (re.match(r"Commencing Stage 1 @ prime (\d+)", l) for l in out) if m]
+        done = [tuple(map(int, m.groups())) for m in
+                (re.match(r"Stage 1 completed at prime (\d+) with (\d+) point-adds and (\d+) point-doubles", l) for l in out) if m]
+        ckpt = [int(m.group(1)) for m in (re.match(r"Saving checkpoint after p=(\d+)", l) for l in out) if m]
+        nr = pyecm.stage1_ranges(c["B1"])
+        assert nr == len(found) == len(pmin) == len(done)
+        adds = dups = 0
+        for r in range(nr):
+            d = pyecm.describe_range(c["B1"], c["B2"], r)
+            assert (d.nprimes, d.lo, d.hi) == found[r] and d.first_prime == pmin[r] and d.last_prime == done[r][0]
+            assert bool(d.checkpoint) == (d.last_prime in ckpt)
+            t = Tape()
+            assert lib.gecm_tape_build_stage1_range(ctypes.byref(t), c["B1"], r, 8) == 0
+            adds += t.ptadds
+            dups += t.ptdups
+            assert (t.last_prime, adds, dups) == done[r], (c["name"], r)
+            lib.gecm_tape_free(ctypes.byref(t))
+
+
+def test_range_tape_is_independent_of_the_worker_threads(lib):
+    lib.gecm_tape_build_stage1_range.argtypes = [ctypes.POINTER(Tape), ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int]
+    lib.gecm_plan_set_prime_range_for_tests.argtypes = [ctypes.c_uint64]
+    lib.gecm_plan_set_prime_range_for_tests.restype = None
+    try:
+        lib.gecm_plan_set_prime_range_for_tests(300000)
+        for r in (0, 1, 3):
+            tapes = []
+            for nt in (1, 3, 8):
+                t = Tape()
+                assert lib.gecm_tape_build_stage1_range(ctypes.byref(t), 1000000, r, nt) == 0
+                tapes.append((bytes(t.ops[:t.len]), t.ptadds, t.ptdups, t.prac_calls, t.last_prime, list(t.rule_count), t.swaps))
+                lib.gecm_tape_free(ctypes.byref(t))
+            assert tapes[0] == tapes[1] == tapes[2]
+        t = Tape()
+        assert lib.gecm_tape_build_stage1_range(ctypes.byref(t), 1000000, 4, 1) == -2     # 4 ranges of 3e5 below 1e6: 0..3
+        assert lib.gecm_tape_build_stage1(ctypes.byref(t), 1000000) == -2                # several ranges: no single tape
+    finally:
+        lib.gecm_plan_set_prime_range_for_tests(0)
+    # one range = the whole of stage 1, as before
+    a, b = Tape(), Tape()
+    assert lib.gecm_tape_build_stage1(ctypes.byref(a), 100000) == 0
+    assert lib.gecm_tape_build_stage1_range(ctypes.byref(b), 100000, 0, 4) == 0
+    assert bytes(a.ops[:a.len]) == bytes(b.ops[:b.len]) and a.last_prime == b.last_prime == 99991
+    lib.gecm_tape_free(ctypes.byref(a))
+    lib.gecm_tape_free(ctypes.byref(b))
+
+
+def test_the_library_was_built_from_this_tree(lib):
+    """gecm_version() carries the hash of the sources every object inside libgecm.so was compiled from (kernel objects,
+    32-lane kernels, device layer, host C; avx-ecm_amd/Makefile).  They must be the tree's: a stale object, a library
+    left over from another commit or a DEV build fails here — and in smoke() on the GPU box — instead of producing
+    numbers for code that is not the code."""
+    import __graft_entry__ as ge
+    lib.gecm_version.restype = ctypes.c_char_p
+    v = lib.gecm_version().decode()
+    assert "MIXED" not in v and "unset" not in v, v
+    ge.check_manifest(v)
+    with pytest.raises(RuntimeError):
+        ge.check_manifest(v.replace("K:", "K:0"))
+    # the command-line driver prints the same string
+    exe = os.path.join(ROOT, "avx-ecm_amd", "avx-ecm")
+    assert os.path.exists(exe)

@@ -1,6 +1,7 @@
 """GPU test of the avx-ecm command line (host/avx_ecm_main.c): same positional arguments as the
-reference, save_b1.txt byte-identical to the file the reference wrote (sha256 held in
-tests/golden/stage1.json), ecm_results.txt factor lines identical for an 8-curve run."""
+reference; save_b1.txt, ecm_results.txt and checkpoint.txt byte-identical to the files the REFERENCE wrote
+(tests/golden/stage1.json, batches.json, multirange.json — made by tests/golden/make_golden.py), for runs of one and
+of several reference batches, one and several threads, one and several prime ranges."""
 import hashlib
 import json
 import os
@@ -14,6 +15,8 @@ from conftest import GOLDEN, ROOT
 pytestmark = pytest.mark.gpu
 EXE = os.path.join(ROOT, "avx-ecm_amd", "avx-ecm")
 S1 = {c["name"]: c for c in json.load(open(os.path.join(GOLDEN, "stage1.json")))}
+BATCHES = json.load(open(os.path.join(GOLDEN, "batches.json")))
+MULTI = json.load(open(os.path.join(GOLDEN, "multirange.json"))) if os.path.exists(os.path.join(GOLDEN, "multirange.json")) else []
 
 
 def _run(args, env=None):
@@ -33,8 +36,8 @@ def test_cli_save_file_and_results(name):
     assert hashlib.sha256(save.encode()).hexdigest() == c["save_sha256"]
     assert "Stage 1 completed at prime" in out and "with %d point-adds and %d point-doubles" % (c["ptadds"], c["ptdups"]) in out
     assert "Choosing MAXBITS = %d, NWORDS = %d" % (c["maxbits"], c["nwords"]) in out
-    if c["curves"] == 8:
-        assert res == c["results_lines"]
+    assert save.splitlines() == c["save_lines"]
+    assert res == c["results_lines"]
     if c["stage2_counts"]:
         assert "performed %d pt-adds, %d inversions, and %d pair-muls in stage 2" % tuple(c["stage2_counts"]) in out
 
@@ -93,16 +96,72 @@ def test_cli_prints_the_reference_banner_lines():
         assert norm(l) in got, l
 
 
+@pytest.mark.parametrize("case", BATCHES, ids=[c["name"] for c in BATCHES])
+def test_cli_reference_batches(case):
+    """More curves than one reference batch (8 x threads).  The reference works batch by batch and stops after the
+    first one in which a curve found a factor (ecm.c:1531-1532); every thread of a batch runs the same eight sigmas
+    when sigma is given (ecm.c:1187), and a factor is labelled curve threads*curve + j*8 + i, thread j, vec i
+    (ecm.c:1356-1366).  One pass on the GPU holds all those batches; the files must be the reference's."""
+    c = case
+    out, save, res = _run([c["N"], c["curves"], c["B1"], c["threads"], c["B2"], c["sigma0"]])
+    assert save.splitlines() == c["save_lines"]
+    assert res == c["results_lines"]
+    want_out = [l for l in c["stdout_lines"] if l.startswith(("found ", "Input has", "Choosing MAXBITS", "performed "))]
+    got = out.splitlines()
+    for l in want_out:
+        assert l in got, l
+    # and the same files when the batches are spread over several passes, pipelined or not
+    for env in ({"GECM_PASS_CURVES": "8"}, {"GECM_PASS_CURVES": "16", "GECM_NO_PIPELINE": "1"},
+                {"GECM_PASS_CURVES": "24", "GECM_CONTEXTS_PER_GPU": "2"}):
+        out2, save2, res2 = _run([c["N"], c["curves"], c["B1"], c["threads"], c["B2"], c["sigma0"]], env=env)
+        assert (save2, res2) == (save, res), env
+
+
 def test_cli_fourth_argument_is_the_reference_s_thread_count():
     """argv[4] is `threads` as in the reference: it rounds the curve count (main.c:585-589: per thread, whole vectors
-    of 8) and is printed; it neither selects GPUs nor fails when it exceeds them.  Curve k gets sigma + k."""
+    of 8), sets the labels and the number of lines per batch, and is printed; it neither selects GPUs nor fails when
+    it exceeds them."""
     c = S1["K1N_two_full_batches_b1_500"]
     out, save, res = _run([c["N"], 20, c["B1"], 16, c["B2"], c["sigma0"]])
     assert "using 16 threads (2 curves/thread)" in out
     lines = save.splitlines()
     assert len(lines) == 16 * 8                                       # 2 curves per thread -> one vector of 8 each
-    assert [int(l.split("SIGMA=")[1].split(";")[0]) for l in lines] == list(range(c["sigma0"], c["sigma0"] + 128))
-    assert lines[:16] == c["save_lines"]                              # the reference's own lines for sigma0 .. +15
+    assert lines == c["save_lines"][:8] * 16                          # every thread: the reference's eight sigmas
+
+
+def _run_many(cmds):
+    """several driver processes at once (each a handful of curves: the GPU has room), one directory each"""
+    import shutil
+    dirs, procs = [], []
+    for args in cmds:
+        d = tempfile.mkdtemp()
+        dirs.append(d)
+        procs.append(subprocess.Popen([EXE] + [str(a) for a in args], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for d, p in zip(dirs, procs):
+        out, _ = p.communicate(timeout=1100)
+        assert p.returncode == 0, out
+        rd = lambda f: open(os.path.join(d, f)).read().splitlines() if os.path.exists(os.path.join(d, f)) else None
+        outs.append((out, rd("save_b1.txt"), rd("checkpoint.txt"), [l for l in (rd("ecm_results.txt") or []) if l.strip()]))
+        shutil.rmtree(d)
+    return outs
+
+
+@pytest.mark.skipif(not MULTI, reason="tests/golden/multirange.json not generated")
+def test_cli_multirange_b1_above_1e8():
+    """B1 = 1.1e8: two prime ranges (ecm.c:1209-1312).  checkpoint.txt after the first (B1 field = 99999989), the
+    doublings repeated and 100000007 skipped in the second, then save_b1.txt — and, in the second case, stage 2 from
+    B1 to 1.3e8.  Byte for byte the files of the reference (three minutes of its time per case; about as long here:
+    eight curves are one wavefront's worth of latency)."""
+    outs = _run_many([[c["N"], c["curves"], c["B1"], 1, c["B2"], c["sigma0"]] for c in MULTI])
+    for c, (out, save, ckpt, res) in zip(MULTI, outs):
+        assert ckpt == c["checkpoint_lines"], c["name"]
+        assert save == c["save_lines"], c["name"]
+        assert res == c["results_lines"], c["name"]
+        got = out.replace("\r", "\n").splitlines()
+        for l in c["stdout_lines"]:
+            if l.startswith(("Found ", "Commencing Stage 1 @", "Stage 1 completed", "Saving checkpoint", "performed ", "found ")):
+                assert l in got, (c["name"], l)
 
 
 def test_cli_two_gpus_write_the_same_files():
@@ -111,13 +170,12 @@ def test_cli_two_gpus_write_the_same_files():
     import pyecm
     if pyecm.device_count() < 2:
         pytest.skip("needs 2 GPUs")
-    c = S1["n415_b1_10000_b2_1e6"]
-    one = _run([c["N"], 64, c["B1"], 1, c["B2"], c["sigma0"]], env={"GECM_GPUS": "1"})
-    two = _run([c["N"], 64, c["B1"], 1, c["B2"], c["sigma0"]], env={"GECM_GPUS": "2"})
+    c = S1["K1N_two_full_batches_b1_500"]
+    one = _run([c["N"], 64, c["B1"], 1, 20000, c["sigma0"]], env={"GECM_GPUS": "1"})
+    two = _run([c["N"], 64, c["B1"], 1, 20000, c["sigma0"]], env={"GECM_GPUS": "2"})
     assert "2 GPU(s)" in two[0] and "1 GPU(s)" in one[0]
     assert one[1] == two[1] and len(one[1].splitlines()) == 64
-    strip = lambda ls: [__import__("re").sub(r"thread \d+, vec \d+", "", l) for l in ls]
-    assert strip(one[2]) == strip(two[2])
+    assert one[2] == two[2]
 
 
 @pytest.mark.parametrize("contexts", [2, 3])
@@ -125,11 +183,21 @@ def test_cli_several_contexts_write_the_same_files(contexts):
     """The same multi-context path on whatever the box has: GECM_CONTEXTS_PER_GPU puts several contexts, each with its
     host thread, on one device (curves split between them, the first stage-2 range's pair map shared, every context's
     tape prepared while its stage-1 kernel runs).  save_b1.txt and ecm_results.txt equal the one-context run's."""
-    c = S1["n415_b1_10000_b2_1e6"]
-    one = _run([c["N"], 72, c["B1"], 1, c["B2"], c["sigma0"]], env={"GECM_GPUS": "1"})
-    many = _run([c["N"], 72, c["B1"], 1, c["B2"], c["sigma0"]], env={"GECM_GPUS": "1", "GECM_CONTEXTS_PER_GPU": str(contexts)})
+    c = S1["K1N_two_full_batches_b1_500"]
+    one = _run([c["N"], 72, c["B1"], 1, 20000, c["sigma0"]], env={"GECM_GPUS": "1"})
+    many = _run([c["N"], 72, c["B1"], 1, 20000, c["sigma0"]], env={"GECM_GPUS": "1", "GECM_CONTEXTS_PER_GPU": str(contexts)})
     assert "%d GPU(s)" % contexts in many[0] and "1 GPU(s)" in one[0]
     assert one[1] == many[1] and len(one[1].splitlines()) == 72
-    strip = lambda ls: [__import__("re").sub(r"thread \d+, vec \d+", "", l) for l in ls]
-    assert strip(one[2]) == strip(many[2])
+    assert one[2] == many[2]
     assert one[1].splitlines()[:len(c["save_lines"])] == c["save_lines"]
+
+
+def test_cli_pipelined_passes_write_the_same_file():
+    """several passes: two sets of contexts alternate, the host work of a pass (curves, lines, files) overlaps the
+    kernels of its neighbours; the file is the one a single pass writes"""
+    c = S1["K1N_two_full_batches_b1_500"]
+    one = _run([c["N"], 4096, 300, 1, 300, 7000])
+    piped = _run([c["N"], 4096, 300, 1, 300, 7000], env={"GECM_PASS_CURVES": "512"})
+    serial = _run([c["N"], 4096, 300, 1, 300, 7000], env={"GECM_PASS_CURVES": "512", "GECM_NO_PIPELINE": "1"})
+    assert len(one[1].splitlines()) == 4096 and one[1] == piped[1] == serial[1]
+    assert "Commencing curves 3584-4095 of 4096" in piped[0]

@@ -164,3 +164,52 @@ def test_oracle_stage2_result_lines_and_counters(orc, name, lanes):
         assert fac == want.get(sigma), (name, lane, sigma)
         assert cnt == case["stage2_counts"]
     orc.orc_destroy(c)
+
+
+# ---- stage 1 above one prime range (ecm.c:1209-1312) ----
+MULTI = json.load(open(os.path.join(GOLDEN, "multirange.json"))) if os.path.exists(os.path.join(GOLDEN, "multirange.json")) else []
+
+
+def _ranges_line(orc, c, sigma, b1, b2, prange, stop_after, b1_field):
+    orc.orc_stage1_ranges_line.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64,
+                                           ctypes.c_int, ctypes.c_uint64, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p,
+                                           ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_int)]
+    line = ctypes.create_string_buffer(8192)
+    cnt = (ctypes.c_uint64 * 3)()
+    ck = ctypes.c_int(0)
+    orc.orc_stage1_ranges_line(c, sigma, b1, b2, prange, stop_after, b1_field, line, len(line), None, 0, cnt, ctypes.byref(ck))
+    return line.value.decode().rstrip("\n"), list(cnt), ck.value
+
+
+def test_oracle_one_range_is_plain_stage1(orc):
+    """the loop over prime ranges with a single range is ecm_stage1 as pinned by stage1.json"""
+    case = [c for c in S1 if c["name"] == "n415_b1_10000"][0]
+    n = int(case["save_lines"][0].split("N=0x")[1].split(";")[0], 16)
+    c = orc.orc_create(str(n).encode(), 52)
+    for k in (0, 7):
+        line, cnt, ck = _ranges_line(orc, c, case["sigma0"] + k, case["B1"], case["B2"], 100000000, 0, case["B1"])
+        assert line == case["save_lines"][k] and cnt[:2] == [case["ptadds"], case["ptdups"]] and ck == 0
+    orc.orc_destroy(c)
+
+
+@pytest.mark.skipif(not MULTI or not os.environ.get("GECM_SLOW_TESTS"),
+                    reason="three minutes of scalar C per lane: set GECM_SLOW_TESTS=1 (run once per change of the oracle's "
+                           "stage 1; result recorded in DESIGN.md)")
+@pytest.mark.parametrize("case", MULTI, ids=[c["name"] for c in MULTI])
+def test_oracle_multirange_against_the_reference_files(orc, case):
+    """lane 0: the checkpoint.txt line after the first range and the save_b1.txt line, as the reference wrote them"""
+    import threading
+    n = int(case["N"])
+    got = {}
+
+    def run(key, stop_after, b1_field):
+        c = orc.orc_create(str(n).encode(), 52)
+        got[key] = _ranges_line(orc, c, case["sigma0"], case["B1"], case["B2"], 100000000, stop_after, b1_field)
+        orc.orc_destroy(c)
+    ts = [threading.Thread(target=run, args=("ckpt", 1, 0)), threading.Thread(target=run, args=("save", 0, case["B1"]))]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert got["ckpt"][0] == case["checkpoint_lines"][0] and got["ckpt"][2] == 1
+    assert got["save"][0] == case["save_lines"][0]
+    done = [l for l in case["stdout_lines"] if l.startswith("Stage 1 completed")]
+    assert "prime %d with %d point-adds and %d point-doubles" % (got["save"][1][2], got["save"][1][0], got["save"][1][1]) in done[-1]
