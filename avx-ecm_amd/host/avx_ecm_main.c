@@ -86,6 +86,9 @@ typedef struct {
     size_t nbatches;           /* reference batches of the run: ceil(per_thread / 8) */
     size_t ub;                 /* distinct curves per reference batch: 8 (fixed sigma) or 8*threads */
     first_range_t fr;
+    gecm_stage1_range_desc *rd;   /* what vececm prints and decides around each prime range (made once, on a helper thread) */
+    pthread_t rd_thread;
+    int rd_pending, rd_rc;
     /* pipeline: passes take the GPUs and write their output in pass order */
     pthread_mutex_t mu;
     pthread_cond_t cv;
@@ -174,6 +177,16 @@ static void plog(pass_t *ps, const char *fmt, ...)
     if (n <= 0) return;
     if (ps->live) { fputs(tmp, stdout); fflush(stdout); }
     else text_add(&ps->log, tmp, (size_t)n < sizeof tmp ? (size_t)n : sizeof tmp - 1);
+}
+
+/* the sieved interval, prime count, first and last prime and checkpoint decision of every stage-1 range: 0.25 s of
+ * sieving per range, done once while the contexts are made and the first curves built */
+static void *describe_ranges(void *arg)
+{
+    run_t *R = (run_t *)arg;
+    for (int r = 0; r < R->nranges && !R->rd_rc; r++)
+        R->rd_rc = gecm_stage1_describe_range(R->B1, R->B2, (uint32_t)r, &R->rd[r]);
+    return NULL;
 }
 
 /* ---- per-GPU jobs of a pass ----------------------------------------------------------------- */
@@ -435,9 +448,14 @@ static void *pass_run(void *arg)
     t = now();
     gecm_stage1_stats st;
     memset(&st, 0, sizeof st);
+    pthread_mutex_lock(&R->mu);
+    if (R->rd_pending) { pthread_join(R->rd_thread, NULL); R->rd_pending = 0; }
+    pthread_mutex_unlock(&R->mu);
+    if (R->rd_rc) { fprintf(stderr, "%s\n", gecm_last_error()); pass_fail(ps); return NULL; }
     for (int r = 0; r < R->nranges; r++) {                                                         /* ecm.c:1209-1312 */
-        gecm_stage1_range_desc rd;
-        if (gecm_stage1_describe_range(R->B1, R->B2, (uint32_t)r, &rd)) { fprintf(stderr, "%s\n", gecm_last_error()); pass_fail(ps); return NULL; }
+        const gecm_stage1_range_desc rd = R->rd[r];
+        /* the reference sieves range 0 once before its first batch (ecm.c:1139-1146) and again whenever a batch
+         * starts after a later range was loaded (ecm.c:1160-1173) */
         if (r > 0 || R->nranges > 1)
             plog(ps, "Found %lu primes in range [%lu : %lu]\n", (unsigned long)rd.nprimes, (unsigned long)rd.lo, (unsigned long)rd.hi);   /* ecm.c:1228 */
         plog(ps, "Commencing Stage 1 @ prime %lu\n", (unsigned long)rd.first_prime);               /* ecm.c:1233 */
@@ -653,6 +671,10 @@ int main(int argc, char **argv)
     R.ub = R.fixed_sigma ? VECLEN : (size_t)VECLEN * (size_t)R.threads;
 
     fputs(prep_log, stdout);          /* "gen: ...", "removing algebraic ...", "commencing parallel ecm on ..." */
+    R.rd = (gecm_stage1_range_desc *)calloc((size_t)R.nranges, sizeof *R.rd);
+    if (!R.rd) { fprintf(stderr, "out of memory\n"); return 2; }
+    R.rd_pending = pthread_create(&R.rd_thread, NULL, describe_ranges, &R) == 0;
+    if (!R.rd_pending) describe_ranges(&R);
     /* passes: as many reference batches as fit FULL_BATCH distinct curves per GPU.  GECM_PASS_CURVES (distinct curves
      * per pass over all GPUs) overrides it for tests. */
     size_t cap = (size_t)FULL_BATCH * (size_t)gpus;
@@ -705,6 +727,9 @@ int main(int argc, char **argv)
     R.fr.U = GECM_S2_DEFAULT_U;
     R.lcg = (uint64_t)(R.t_start * 1e6) * 0x9E3779B97F4A7C15ULL + (uint64_t)getpid();
 
+    if (R.rd_pending) { pthread_join(R.rd_thread, NULL); R.rd_pending = 0; }
+    if (!R.rd_rc && R.nranges == 1)                                                /* ecm.c:1139-1146 */
+        printf("Found %lu primes in range [%lu : %lu]\n", (unsigned long)R.rd[0].nprimes, (unsigned long)R.rd[0].lo, (unsigned long)R.rd[0].hi);
     static pass_t pass[2];
     int running[2] = {0, 0};
     for (size_t pi = 0; pi < npasses; pi++) {

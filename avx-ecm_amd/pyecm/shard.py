@@ -42,7 +42,9 @@ def allreduce_found(dist, local_found_global_index, total, device="cpu"):
     factor over all ranks, or None."""
     import torch
     t = torch.tensor([encode_found(local_found_global_index, total)], dtype=torch.int64, device=device)
-    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist is not None and dist.is_initialized():
+        # also for a world of one: a single rank launched through torch.distributed.run runs the very collective the
+        # N-rank job runs (RCCL on a device tensor), so the path is exercised on whatever hardware there is
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return decode_found(int(t.item()), total)
 

@@ -30,6 +30,9 @@ Extra objects on the line:
   saturated     131072 curves in one launch (one curve per lane, 2 wavefronts per SIMD)
   config2 / config4   BASELINE configs[2] (4096 x 831-bit, B1=1e6) and configs[4] (1023-bit, 32-bit
                 reference limbs, B1=1e5), one warm-up and one step each
+  bits624       the 624-bit class of north_star (4096 x 623-bit, B1=1e6), likewise
+  ranks         the world size as the process group reports it, every rank's curve range, device and kernel time, and
+                how many found-record all-reduces each rank really ran
 """
 import argparse
 import ctypes
@@ -285,6 +288,7 @@ def main():
 
     kernel_ms = []
     found_log = []
+    collectives = [0]          # found-record all-reduces that really went through the process group
 
     prepared = []
 
@@ -305,6 +309,8 @@ def main():
         nf, first = eng.scan_factors(1)
         g = shard.allreduce_found(dist, None if first is None else lo + first, total, device=dev)
         found_log.append((nf, g))
+        if dist is not None:
+            collectives[0] += 1
 
     # ---- step count from the budget: one probe step (the first warm-up step, or an extra one) ----
     t0 = time.perf_counter()
@@ -331,6 +337,20 @@ def main():
     lanes = eng.lanes_per_curve()
     kname = kernel_name(lanes, cfg.dev_limbs)
 
+    # what every rank did, gathered so that the line checks itself: the world size as the process group reports it,
+    # each rank's curve range, device and kernel time
+    mine = [float(rank), float(lo), float(hi), float(devno), sum(kernel_ms) / max(1, len(kernel_ms)),
+            min(kernel_ms) if kernel_ms else 0.0, max(kernel_ms) if kernel_ms else 0.0, float(collectives[0])]
+    if dist is not None:
+        tm = torch.tensor(mine, dtype=torch.float64, device=dev)
+        parts = [torch.zeros_like(tm) for _ in range(dist.get_world_size())]
+        dist.all_gather(parts, tm)
+        per_rank = [[float(x) for x in p.tolist()] for p in parts]
+        world_reported = dist.get_world_size()
+    else:
+        per_rank = [mine]
+        world_reported = None
+
     stage2 = None
     if a.b2 > a.b1 and not a.no_engine:
         # not part of the metric: one pass of the stage-2 continuation on every rank's resident batch
@@ -355,11 +375,24 @@ def main():
         mul, sqr, mads, w52 = work_per_curve(st.ptadds, st.ptdups, cfg.dev_limbs, cfg.nwords)
         kms = sum(kernel_ms) / len(kernel_ms)
         achieved = mads * a.curves / (kms * 1e-3)
-        traffic = None
+        # counters of this command from the committed rocprofv3 PMC passes (profiles/pmc_latest.json) — only if they
+        # were taken on THIS build: the file carries the source hashes gecm_version() reports (the kernels' K/R/D parts)
+        traffic = valu_per_mad = valu_active = None
+        build = "" if a.no_engine else pyecm.lib.gecm_version().decode()
+        build_dev = " ".join(f for f in build.split() if f[:2] in ("K:", "R:", "D:"))
+        pmc_state = "no profiles/pmc_latest.json"
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
-            if pm.get("kernel") == kname and pm.get("curves") == a.curves and pm.get("B1") == a.b1:
+            if pm.get("kernel") != kname or pm.get("curves") != a.curves or pm.get("B1") != a.b1:
+                pmc_state = "committed profile is of another workload (%s, %s curves, B1 %s)" % (pm.get("kernel"), pm.get("curves"), pm.get("B1"))
+            elif pm.get("build") != build_dev:
+                pmc_state = "committed profile was taken on another build (%s), this is %s" % (pm.get("build"), build_dev)
+            else:
+                pmc_state = "profiles/pmc_latest.json, same build"
                 traffic = pm["hbm_bytes_per_launch_corrected"]
+                waves = pm["counters"]["SQ_WAVES"]
+                valu_per_mad = pm["valu_insts_per_wave"] * waves / (mads * a.curves / 64.0)
+                valu_active = pm["valu_active_share_of_wave_cycles"]
         except Exception:
             pass
         roof = {
@@ -367,7 +400,16 @@ def main():
             "achieved": achieved / 1e12, "peak": PEAK_MAD_PER_S / 1e12, "unit": "Tmad/s (v_mad_u64_u32 lane-ops)",
             "frac": achieved / PEAK_MAD_PER_S, "traffic": traffic,
             "traffic_note": "HBM bytes per launch from rocprofv3 PMC passes of this command (profiles/), FETCH_SIZE x2 "
-                            "per the gfx950 correction; null if no matching profile is committed",
+                            "per the gfx950 correction; null unless the committed profile is of this workload AND this build. "
+                            "It is ~30x the algorithmic bytes and costs nothing: the op tape (2.1 MB at B1=1e6) is read by "
+                            "every one of the 2048 wavefronts through scalar loads, a few of those passes miss L2/MALL; at "
+                            "~15 MB/s that is 2e-6 of the HBM peak (the kernel is bound by VALU issue)",
+            "pmc": pmc_state,
+            "valu_insts_per_algorithmic_mad": valu_per_mad,
+            "valu_insts_note": "SQ_INSTS_VALU over all wavefronts / (algorithmic lane multiply-adds / 64): VALU instructions "
+                               "issued per wave-level multiply-add the product-scanning count asks for; 1.0 would be a kernel "
+                               "of nothing but useful v_mad_u64_u32",
+            "valu_active_share_of_wave_cycles": valu_active,
             "kernel_ms_avg": kms, "mads_per_curve": mads,
             "mads_note": "algorithmic: product-scanning multiply 2n^2+n, square n(n+1)/2+n^2+n on n=%d limbs of 28 bits; "
                          "a layout that spends more instructions than that scores lower, not higher" % cfg.dev_limbs,
@@ -388,9 +430,19 @@ def main():
                                    "format 52-bit NWORDS=%d" % (a.curves, a.bits, a.bits, a.b1, cfg.nwords),
                        "curves_per_gpu": a.curves, "bits": a.bits, "B1": a.b1, "lanes_per_curve": lanes,
                        "curves_with_factor_last_step": found_log[-1][0],
-                       "parallelism": "curve batch split across %d GPU(s) on the host, no data-path collective, "
-                                      "1 all-reduce (%s) of the found record per step"
-                                      % (world, "RCCL" if a.backend == "nccl" else a.backend)},
+                       "parallelism": ("curve batch split across %d GPU(s) on the host, no data-path collective, "
+                                       "1 all-reduce (%s) of the found record per step"
+                                       % (world, "RCCL" if a.backend == "nccl" else a.backend)) if dist is not None else
+                                      "one process, one GPU: no collective (single process; launch through "
+                                      "torch.distributed.run to make the process group and run the all-reduce)"},
+            "ranks": {"process_group": None if dist is None else a.backend,
+                      "world_size_reported_by_process_group": world_reported,
+                      "found_record_allreduces_per_rank_timed_and_warmup": [int(r[7]) for r in per_rank],
+                      "kernel_ms_avg_min_over_ranks": min(r[4] for r in per_rank),
+                      "kernel_ms_avg_max_over_ranks": max(r[4] for r in per_rank),
+                      "per_rank": [{"rank": int(r[0]), "global_curves": [int(r[1]), int(r[2])], "device": int(r[3]),
+                                    "kernel_ms_avg": r[4], "kernel_ms_min": r[5], "kernel_ms_max": r[6]} for r in per_rank],
+                      "curves_total": total},
             "roofline": roof,
         }
         if a.no_engine:
@@ -410,7 +462,7 @@ def main():
                 line["cpu_baseline"] = cpu_baseline(n, a.b1, budget_s=min(30.0, max(8.0, left() - 15.0)))
             except Exception as ex:
                 line["cpu_baseline"] = {"error": str(ex)}
-        extras = [] if a.no_extras else ["config2", "config4", "saturated", "special_form"]
+        extras = [] if a.no_extras else ["config2", "bits624", "config4", "saturated", "special_form"]
         per_curve_s = dt / steps / a.curves          # of the headline layout; the estimates below are upper bounds
         for name in extras:
             try:
@@ -427,6 +479,19 @@ def main():
                                   "value": 4096 / w, "unit": "curves/s", "kernel_ms": k, "lanes_per_curve": e2.lanes_per_curve(),
                                   "dev_limbs": e2.cfg.dev_limbs, "valu_frac": m2 * 4096 / (k * 1e-3) / PEAK_MAD_PER_S}
                     e2.close()
+                elif name == "bits624":          # north_star's third size: 624-bit class (623-bit N), same batch and B1
+                    if left() < 2 * 2.5 * t_probe + 20:
+                        raise TimeoutError("budget")
+                    n6 = random.Random(623).getrandbits(623) | (1 << 622) | 1
+                    e6 = pyecm.Engine(n6, digitbits=52, device=devno)
+                    e6.build_curves(list(range(1000, 1000 + 4096)))
+                    w, k = timed_pass(e6, a.b1, True)
+                    s6 = e6.stage1_stats()
+                    m6 = work_per_curve(s6.ptadds, s6.ptdups, e6.cfg.dev_limbs, e6.cfg.nwords)[2]
+                    line[name] = {"workload": "4096 curves, 623-bit random odd N (seed 623), B1=%d" % a.b1,
+                                  "value": 4096 / w, "unit": "curves/s", "kernel_ms": k, "lanes_per_curve": e6.lanes_per_curve(),
+                                  "dev_limbs": e6.cfg.dev_limbs, "valu_frac": m6 * 4096 / (k * 1e-3) / PEAK_MAD_PER_S}
+                    e6.close()
                 elif name == "config4":          # BASELINE configs[4]: DIGITBITS=32 boundary, 1024-bit class, B1=1e5
                     if left() < 2 * 1.0 * t_probe + 15:
                         raise TimeoutError("budget")

@@ -231,8 +231,16 @@ def gen_stage2_acc():
     k1n = int([l for l in open("/root/reference/test.csh").read().splitlines() if "7372562557" in l][0].split()[1])
     t35 = int(open("/root/reference/test_t35.csh").read().splitlines()[45].split()[1]) if os.path.exists("/root/reference/test_t35.csh") else k1n
     M = lambda e: (1 << e) - 1
-    cases = []
+    path = os.path.join(HERE, "stage2_acc.json")
+    cases = json.load(open(path)) if os.path.exists(path) and "--keep" in sys.argv else []
+    have = {c["name"] for c in cases}
+    t35_sigma = int(open("/root/reference/test_t35.csh").read().splitlines()[45].split()[6]) if os.path.exists("/root/reference/test_t35.csh") else 100
     for name, digitbits, n, b1, b2, sigma0 in (("K1N_b1_2000_b2_1e5", 52, k1n, 2000, 100000, 100),
+                                               # BASELINE's own size (configs[3]: B1 = 1e6, B2 = 1e8, D = 2310, U = 16): the
+                                               # reference's stage-2 KAT (test_t35.csh line 46: lane 0 finds its PRP31) and
+                                               # the 412-bit N of test.csh (416-bit class, no factor found)
+                                               ("T35_46_b1_1e6_b2_1e8", 52, t35, 1000000, 100000000, t35_sigma),
+                                               ("K1N_b1_1e6_b2_1e8", 52, k1n, 1000000, 100000000, 4000),
                                                ("K1N_b1_5000_b2_3e5", 52, k1n, 5000, 300000, 200),
                                                ("K1N_b1_3000_b2_150000", 52, k1n, 3000, 150000, 500),
                                                ("T35N_b1_1000_b2_50000", 52, t35, 1000, 50000, 42),
@@ -242,6 +250,8 @@ def gen_stage2_acc():
                                                ("M607xM127xM107xM89xM61_d32_b1_500_b2_30000", 32,
                                                 M(607) * M(127) * M(107) * M(89) * M(61), 500, 30000, 900),
                                                ("M521xM127_b1_1200_b2_60000", 52, M(521) * M(127), 1200, 60000, 1100)):
+        if name in have:
+            continue
         print("stage2acc:", name, flush=True)
         exe = os.path.join(REFDIR, "avx-ecm-%d-tap" % digitbits)
         veclen = 8 if digitbits == 52 else 16
@@ -263,7 +273,7 @@ def gen_stage2_acc():
                       "U": int(w.group(3)) if w else None,
                       "stage2_counts": [int(x) for x in s2.groups()], "acc_hex": [r[2] for r in last],
                       "results_lines": res})
-    json.dump(cases, open(os.path.join(HERE, "stage2_acc.json"), "w"), indent=1)
+    json.dump(cases, open(path, "w"), indent=1)
 
 
 def semiprime_204():

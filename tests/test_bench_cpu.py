@@ -59,6 +59,30 @@ def test_gpus_2_starts_two_ranks_and_prints_one_line():
     assert "rehearsal" in lines[0]
 
 
+def test_eight_ranks_rehearsal_line_checks_itself():
+    """the N = 8 launch the driver makes, rehearsed on CPU (gloo, engine stubbed): the line carries the world size the
+    process group reports, every rank's contiguous curve range and the number of found-record all-reduces each rank
+    really ran (one per step, warm-up included)"""
+    p, lines = _run_bench("--gpus", "8", "--backend", "gloo", "--no-engine", "--steps", "2", "--warmup", "1")
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = lines[0]
+    r = d["ranks"]
+    assert d["n_gpus"] == 8 and r["world_size_reported_by_process_group"] == 8 and r["process_group"] == "gloo"
+    assert r["curves_total"] == 8 * 4096
+    assert [x["global_curves"] for x in r["per_rank"]] == [[4096 * k, 4096 * (k + 1)] for k in range(8)]
+    assert [x["rank"] for x in r["per_rank"]] == list(range(8))
+    assert r["found_record_allreduces_per_rank_timed_and_warmup"] == [3] * 8
+    assert "gloo" in d["config"]["parallelism"]
+
+
+def test_single_process_line_says_there_is_no_collective():
+    p, lines = _run_bench("--gpus", "1", "--no-engine", "--steps", "1", "--warmup", "0")
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = lines[0]
+    assert "no collective" in d["config"]["parallelism"] and "RCCL" not in d["config"]["parallelism"]
+    assert d["ranks"]["process_group"] is None and d["ranks"]["found_record_allreduces_per_rank_timed_and_warmup"] == [0]
+
+
 def test_gpus_must_match_world_size():
     import subprocess
     import sys
@@ -76,3 +100,6 @@ def test_committed_pmc_summary_is_for_the_headline_kernel():
     assert pm["kernel"] == _bench().kernel_name(32, 15)
     assert pm["curves"] == 4096 and pm["B1"] == 1000000
     assert pm["hbm_bytes_per_launch_corrected"] > 0
+    # and it names the build it was taken on: bench.py shows its counters only on that build (roofline.pmc says which)
+    import re
+    assert re.fullmatch(r"K:[0-9a-f]{16} R:[0-9a-f]{16} D:[0-9a-f]{16}", pm["build"]), pm.get("build")

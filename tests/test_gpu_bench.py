@@ -38,6 +38,11 @@ def test_bench_as_a_rank_under_torch_distributed_run():
     d = _line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                "--master-port", "29541", "bench.py"] + ARGS)
     assert d["n_gpus"] == 1 and "RCCL" in d["config"]["parallelism"] and d["value"] > 0
+    # the found-record all-reduce really ran, over RCCL, on a device tensor: once per step, warm-up included
+    r = d["ranks"]
+    assert r["process_group"] == "nccl" and r["world_size_reported_by_process_group"] == 1
+    assert r["found_record_allreduces_per_rank_timed_and_warmup"] == [3]
+    assert r["per_rank"][0]["global_curves"] == [0, 256] and r["per_rank"][0]["kernel_ms_avg"] > 0
 
 
 def test_bench_two_ranks_with_engines_on_one_gpu():
@@ -48,5 +53,23 @@ def test_bench_two_ranks_with_engines_on_one_gpu():
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0
     assert d["config"]["curves_per_gpu"] == 256
     assert "gloo" in d["config"]["parallelism"]
+    r = d["ranks"]
+    assert r["world_size_reported_by_process_group"] == 2 and r["curves_total"] == 512
+    assert [x["global_curves"] for x in r["per_rank"]] == [[0, 256], [256, 512]]
+    assert r["found_record_allreduces_per_rank_timed_and_warmup"] == [3, 3]
     one = _line([sys.executable, "bench.py"] + ARGS)
     assert d["config"]["curves_with_factor_last_step"] >= 0 and one["n_gpus"] == 1
+
+
+def test_bench_four_ranks_rehearsal_on_one_gpu():
+    """the driver's multi-GPU launch rehearsed on the box's one GPU: four ranks (the box allows six processes on the
+    card), each with its own engine and its own 128 curves on device LOCAL_RANK modulo the visible devices, collectives
+    over gloo.  The line adds up the ranks' curves and shows every rank's range and kernel time."""
+    d = _line([sys.executable, "bench.py", "--gpus", "4", "--backend", "gloo", "--steps", "2", "--warmup", "1", "--b1", "20000",
+               "--b2", "0", "--curves", "128", "--no-extras", "--no-cpu-baseline"])
+    r = d["ranks"]
+    assert d["n_gpus"] == 4 and r["world_size_reported_by_process_group"] == 4 and r["curves_total"] == 512
+    assert [x["global_curves"] for x in r["per_rank"]] == [[128 * k, 128 * (k + 1)] for k in range(4)]
+    assert all(x["kernel_ms_avg"] > 0 for x in r["per_rank"])
+    assert r["kernel_ms_avg_min_over_ranks"] <= r["kernel_ms_avg_max_over_ranks"]
+    assert abs(d["value"] - 512 * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) < 1e-6 * d["value"]

@@ -22,7 +22,9 @@ def test_argument_and_state_errors():
     with pytest.raises(pyecm.GecmError):
         eng.stage1(1)                                      # B1 < 2
     with pytest.raises(pyecm.GecmError):
-        eng.stage1(10 ** 9)                                # more than one prime range
+        eng.stage1(10 ** 13)                               # beyond the 1e12 the ABI takes (1e9 is ten prime ranges: fine)
+    with pytest.raises(pyecm.GecmError, match="prime range"):
+        eng.stage1_range(3 * 10 ** 8, 3)                   # ranges 0, 1, 2 only
     with pytest.raises(pyecm.GecmError, match="stage 1"):
         eng.stage2_init()                                  # stage 2 before stage 1
     eng.stage1(100)

@@ -94,3 +94,41 @@ def test_config3_slice_stage2_4096_curves_b2_1e8():
     assert eng.download_acc()[0] == acc_big
     assert eng.stage2_factor(0) == (want, True)
     eng.close()
+
+
+S2ACC = {c["name"]: c for c in json.load(open(os.path.join(GOLDEN, "stage2_acc.json")))}
+
+
+@pytest.mark.parametrize("name", ["T35_46_b1_1e6_b2_1e8", "K1N_b1_1e6_b2_1e8"])
+def test_config3_slice_accumulators_equal_the_reference_s_stg2acc(name):
+    """BASELINE configs[3]'s per-GPU slice — 4096 curves, B1 = 1e6, B2 = 1e8, D = 2310, U = 16 — with the eight curves
+    of a reference run (tests/golden/stage2_acc.json: work->stg2acc as the reference holds it at ecm.c:1489, tapped by
+    oracle/ref_tap.c) placed at the ends and the middle of the batch, wavefront boundaries included: the accumulator
+    of every one of them is the reference's, bit for bit, in the layouts a batch of this size runs in (32 lanes per
+    curve in stage 1; 32 sub-sequences and 64 pair-walk slices per curve in stage 2)."""
+    import pyecm
+    case = S2ACC[name]
+    n = int(case["N"])
+    at = [0, 63, 64, 2049, 4095, 1, 2048, 4032]
+    sig = list(range(700000, 700000 + 4096))
+    for k, lane in enumerate(at):
+        sig[lane] = case["sigma0"] + k
+    eng = pyecm.Engine(n)
+    assert eng.cfg.nwords == case["nwords"]
+    eng.build_curves(sig)
+    eng.stage1(case["B1"])
+    assert eng.lanes_per_curve() == 32
+    eng.stage2(case["B2"])
+    st = eng.stage2_stats()
+    assert (st.D, st.U, st.L) == (case["D"], case["U"], case["L"]) == (2310, 16, 32)
+    assert [st.ptadds, st.numinv, st.paired] == case["stage2_counts"] == [79886, 1341, 3008627]
+    acc = eng.download_acc()
+    assert [acc[lane] for lane in at] == [int(h, 16) for h in case["acc_hex"]]
+    found = {int(re.search(r"vec (\d+),", l).group(1)): int(re.search(r"factor (\d+) in stage 2", l).group(1))
+             for l in case["results_lines"] if "in stage 2" in l}
+    eng.scan_factors(2)
+    for k, lane in enumerate(at):
+        f = eng.stage2_factor(lane)
+        assert (f[0] if f else None) == found.get(k), (k, lane)
+        assert eng.curve_flag(2, lane) == (k in found)
+    eng.close()

@@ -86,7 +86,11 @@ def test_stage2_accumulator_equals_reference_stg2acc(case):
     assert (st.D, st.U, st.L) == (case["D"], case["U"], case["L"])
     assert [st.ptadds, st.numinv, st.paired] == case["stage2_counts"]
     assert eng.download_acc() == [int(h, 16) for h in case["acc_hex"]]
-    assert all(eng.stage2_factor(k) is None for k in range(case["curves"]))
+    found = {int(re.search(r"vec (\d+),", l).group(1)): int(re.search(r"factor (\d+) in stage 2", l).group(1))
+             for l in case["results_lines"] if "in stage 2" in l}
+    for k in range(case["curves"]):
+        f = eng.stage2_factor(k)
+        assert (f[0] if f else None) == found.get(k), k
     eng.close()
 
 
