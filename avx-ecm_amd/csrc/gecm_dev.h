@@ -9,6 +9,7 @@
 #define GECM_DEV_H
 #include <stddef.h>
 #include <stdint.h>
+#include "gecm_ops.h"
 #include "gecm_rowk.h"
 #ifdef __cplusplus
 extern "C" {
@@ -16,7 +17,6 @@ extern "C" {
 
 typedef struct gecm_dev gecm_dev;
 
-enum { GECM_L0_MUL = 0, GECM_L0_SQR = 1, GECM_L0_ADD = 2, GECM_L0_SUB = 3, GECM_L0_ADDSUB = 4 };
 
 int gecm_dev_count(void);
 /* hashes of the sources the device objects were compiled from: "K:.. R:.. D:.." (Makefile; K = MIXED if the kernel
@@ -42,6 +42,8 @@ int gecm_dev_set_tape(gecm_dev *d, const uint8_t *tape, size_t len);
  * too small to fill the chip), 0 = let the device layer choose from the batch size and CU count */
 int gecm_dev_stage1(gecm_dev *d, int lanes_per_curve);
 int gecm_dev_auto_lanes(gecm_dev *d);
+/* launches of the last gecm_dev_stage1 finished so far / made (a long tape is cut into several, gecm_dev_set_tape) */
+int gecm_dev_stage1_progress(gecm_dev *d, uint32_t *done, uint32_t *total);
 /* constants of the 32-lanes-per-curve kernel (csrc/gecm_row.hpp): nq limbs per lane, rows per multiply
  * (gecm_row_shape), GECM_ROW_KINDS x
  * GECM_ROW_WORDS words (N' = m*N = -1 mod 2^28; N; entry factor; R mod N; K' of N), limb j at word j */
@@ -51,6 +53,8 @@ int gecm_dev_set_rowconst(gecm_dev *d, int nq, int rows, const uint32_t *words);
 int gecm_dev_fform_generic_limbs(int nl);
 void gecm_dev_set_fform(gecm_dev *d, int form);   /* +1: 2^k - 1, -1: 2^k + 1, 2: 2^k - c (limbs 0, 1 below F), 0: off */
 int gecm_dev_last_lanes(gecm_dev *d);
+/* name of the stage-1 kernel the last launch ran, as rocprofv3 prints it ("k_stage1_rowp<1, 16>") */
+const char *gecm_dev_last_kernel(gecm_dev *d);
 int gecm_dev_sync(gecm_dev *d);
 float gecm_dev_last_kernel_ms(gecm_dev *d);
 /* canonical Montgomery-form X, Z (what P holds after ecm_stage1 in the reference, modulo R) */

@@ -36,6 +36,9 @@ extern "C" const int *gecm_dev_supported_nl(void) { return k_supported_nl; }
 #define GECM_S2_WAVES_PER_SIMD 16         // wavefronts per SIMD a pair-walk launch is cut up for (gecm_dev_s2_init)
 #endif
 #define GECM_S2_MAX_SLICES 64
+#ifndef GECM_ROW_DEFAULT_SMALL
+#define GECM_ROW_DEFAULT_SMALL 0   // 32-lane kernel variant for batches up to 2 wavefronts per SIMD (row_a_lds)
+#endif
 struct gecm_dev {
     int device = 0;
     int nl = 0;
@@ -45,6 +48,8 @@ struct gecm_dev {
     uint32_t *dX = nullptr, *dZ = nullptr, *dS = nullptr, *dT0 = nullptr, *dT1 = nullptr;
     uint32_t *dTape = nullptr;
     size_t tape_len = 0, tape_cap = 0;
+    std::vector<hipEvent_t> cut_events;   // one per stage-1 launch of the last gecm_dev_stage1 (progress of a long tape)
+    size_t cut_launches = 0;
     std::vector<size_t> tape_cuts;   // byte offsets at which a stage-1 launch may start (gecm_dev_set_tape), first = 0, last = tape_len
     // stage 2
     std::vector<uint32_t> r3;
@@ -69,6 +74,7 @@ struct gecm_dev {
     int fform = 0;        // +1 / -1 / 2: modulus is 2^k - 1 / 2^k + 1 / 2^k - c and stage 1 uses the special multiply (gecm_dev_set_fform)
     int cus = 0;          // compute units of the device (4 SIMDs each)
     int last_lanes = 0;   // lanes per curve the last stage-1 launch used
+    std::string last_kernel;   // and the kernel's name as rocprofv3 prints it
 };
 
 // ---- source manifest (Makefile): "K:<hash of the kernel objects' sources, or MIXED> R:<rowk> D:<this file>"
@@ -194,6 +200,7 @@ static void free_s2(gecm_dev *d)
 
 extern "C" void gecm_dev_close(gecm_dev *d)
 {
+    if (d) for (hipEvent_t e : d->cut_events) (void)hipEventDestroy(e);
     if (!d) return;
     (void)hipSetDevice(d->device);
     free_state(d);
@@ -351,16 +358,19 @@ extern "C" int gecm_dev_auto_lanes(gecm_dev *d)
     return (r == 0 || r > full / 4 * 3) ? 1 : 2;
 }
 
-/* 32-lane kernel: operand broadcasts through the LDS crossbar from 3 wavefronts per SIMD up (tools/row_check.py);
- * GECM_ROW_ALDS=0/1 overrides for experiments */
+/* 32-lane kernel, how the scanned operand of a multiply reaches its row (csrc/gecm_row.hpp): 0 = DPP broadcasts, 1 =
+ * ds_swizzle through the LDS crossbar (best from 3 wavefronts per SIMD up, tools/row_check.py), 2 = point forms kept in
+ * LDS and read one multiply ahead (k_stage1_rowp: the fewest VALU instructions; what a batch at up to 2 wavefronts per
+ * SIMD — BASELINE configs[1] — is short of).  GECM_ROW_ALDS=0/1/2 overrides for experiments. */
 static int row_a_lds(const gecm_dev *d)
 {
     const char *e = getenv("GECM_ROW_ALDS");
-    if (e && (e[0] == '0' || e[0] == '1')) return e[0] == '1';
-    return d->stride > (size_t)d->cus * 16;
+    if (e && e[0] >= '0' && e[0] <= '2' && !e[1]) return e[0] - '0';
+    return d->stride > (size_t)d->cus * 16 ? 1 : GECM_ROW_DEFAULT_SMALL;
 }
 
 extern "C" int gecm_dev_last_lanes(gecm_dev *d) { return d->last_lanes; }
+extern "C" const char *gecm_dev_last_kernel(gecm_dev *d) { return d->last_kernel.c_str(); }
 
 extern "C" int gecm_dev_fform_generic_limbs(int nl)
 {
@@ -395,8 +405,25 @@ extern "C" int gecm_dev_stage1(gecm_dev *d, int lanes_per_curve)
         return -2;
     }
     d->last_lanes = lanes_per_curve;
+    {
+        char nm[96];
+        const int mode = row_a_lds(d);
+        if (lanes_per_curve == 32 && mode == 2) snprintf(nm, sizeof nm, "k_stage1_rowp<%d, %d>", d->row_nq, d->row_rows);
+        else if (lanes_per_curve == 32) snprintf(nm, sizeof nm, "k_stage1_row<%d, %d, %s>", d->row_nq, d->row_rows, mode ? "true" : "false");
+        else if (lanes_per_curve == 8) snprintf(nm, sizeof nm, "k_stage1_quad<%d>", d->nl);
+        else if (d->fform) snprintf(nm, sizeof nm, "%s<%d, Mod%c<%d> >", lanes_per_curve == 2 ? "k_stage1_pair_f" : "k_stage1_f", d->nl,
+                                    d->fform == 2 ? 'C' : d->fform > 0 ? 'F' : 'P', d->nl);
+        else snprintf(nm, sizeof nm, "%s<%d>", lanes_per_curve == 2 ? "k_stage1_pair" : "k_stage1", d->nl);
+        d->last_kernel = nm;
+    }
     gecm_modconst mc = modconst(d);
     HIPCHK(hipEventRecord(d->ev0, d->stream));
+    d->cut_launches = d->tape_cuts.size() - 1;
+    while (d->cut_events.size() < d->cut_launches) {
+        hipEvent_t e;
+        HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        d->cut_events.push_back(e);
+    }
     for (size_t cut = 0; cut + 1 < d->tape_cuts.size(); cut++) {
     const uint32_t *tp = d->dTape + d->tape_cuts[cut] / 4;
     const uint32_t tl = (uint32_t)(d->tape_cuts[cut + 1] - d->tape_cuts[cut]);
@@ -434,10 +461,25 @@ extern "C" int gecm_dev_stage1(gecm_dev *d, int lanes_per_curve)
         g_err = "unsupported nl";
         return -2;
     }
+    HIPCHK(hipEventRecord(d->cut_events[cut], d->stream));
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(d->ev1, d->stream));
     d->timed = true;
+    return 0;
+}
+
+/* launches of the last gecm_dev_stage1 that have finished / that it made (a long tape runs as several) */
+extern "C" int gecm_dev_stage1_progress(gecm_dev *d, uint32_t *done, uint32_t *total)
+{
+    uint32_t n = 0;
+    for (size_t i = 0; i < d->cut_launches; i++) {
+        if (hipEventQuery(d->cut_events[i]) != hipSuccess) break;    // in order on one stream
+        n++;
+    }
+    (void)hipGetLastError();
+    if (done) *done = n;
+    if (total) *total = (uint32_t)d->cut_launches;
     return 0;
 }
 

@@ -1,7 +1,7 @@
 // gecm_kernels.hip — HIP kernels of libgecm for ONE limb count (compile with -DGECM_NL=<n>).
 // One translation unit per limb count so the (large, fully unrolled) kernels build in parallel.
 // See gecm_field.hpp / gecm_curve.hpp for the arithmetic; DESIGN.md for the layout.
-#include "gecm_dev.h"
+#include "gecm_ops.h"
 #include "gecm_launch.h"
 #include "gecm_curve.hpp"
 #include "gecm_stage2.hpp"

@@ -189,6 +189,53 @@ __device__ __forceinline__ void fer_mul(FeR<NQ> &r, const FeR<NQ> &a, const FeR<
     for (int t = 1; t < NQ; t++) r.v[t] = lo[t];
 }
 
+// The same multiply with the limbs of 4a ALREADY in every lane of the row (Ab[j] = 4 x limb j of a): no operand
+// broadcast in the rows at all.  This is what the multiplies of the LDS-prefetch kernel run (run_tape_row_lds below):
+// their broadcast operand is a point form that was written to LDS when the point was made and is read back, four
+// limbs per ds_read_b128 with every lane of a row reading the same address, one multiply ahead of its use.
+template <int NQ, int ROWS, bool RHO1>
+__device__ __forceinline__ void fer_mul_pre(FeR<NQ> &r, const int32_t (&Ab)[ROWS], const FeR<NQ> &b, const RowMod<NQ> &m)
+{
+    static_assert(ROWS % NQ == 0 && ROWS <= 16 * NQ, "whole lanes, at most 16 of them");
+    int32_t b4[NQ];
+#pragma unroll
+    for (int t = 0; t < NQ; t++) b4[t] = (int32_t)((uint32_t)b.v[t] << 2);
+    int64_t T[NQ];
+#pragma unroll
+    for (int t = 0; t < NQ; t++) T[t] = 0;
+    static_for<0, ROWS>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        constexpr int rot = i % NQ, nxt = (i + 1) % NQ;
+        if constexpr (i == 0) smad(T[rot], Ab[0], b4[0]);
+#pragma unroll
+        for (int t = 1; t < NQ; t++) smad(T[(t + rot) % NQ], Ab[i], b4[t]);
+        uint32_t qs = (uint32_t)T[rot];
+        if (!RHO1) qs *= m.rho;
+        const uint32_t Q = row_bcast<0>(qs);
+#pragma unroll
+        for (int t = 0; t < NQ; t++) umad(T[(t + rot) % NQ], Q, m.n[t]);
+        const int32_t hi = (int32_t)(T[rot] >> 32);
+        const uint32_t lo = row_dpp<GECM_DPP_ROW_SHL1>((uint32_t)T[rot]);
+        T[rot] = (int64_t)(uint64_t)lo;
+        if constexpr (i + 1 < ROWS) T[nxt] = smad16_smad(hi, T[nxt], Ab[i + 1], b4[0]);
+        else T[nxt] = smad16(hi, T[nxt]);
+    });
+    int32_t lo[NQ];
+    int64_t carry = 0;
+#pragma unroll
+    for (int t = 0; t < NQ - 1; t++) {
+        const int64_t u = (T[t] >> 4) + carry + (1 << 27);
+        carry = u >> GECM_LIMB_BITS;
+        lo[t] = (int32_t)((uint32_t)u & GECM_LIMB_MASK) - (1 << 27);
+    }
+    const int32_t ut = (int32_t)(T[NQ - 1] >> 4) + (int32_t)carry + (1 << 27);
+    lo[NQ - 1] = (int32_t)((uint32_t)ut & GECM_LIMB_MASK) - (1 << 27);
+    const int32_t below = (int32_t)row_dpp<GECM_DPP_ROW_SHR1>((uint32_t)(ut >> GECM_LIMB_BITS));
+    r.v[0] = lo[0] + below;
+#pragma unroll
+    for (int t = 1; t < NQ; t++) r.v[t] = lo[t];
+}
+
 // A point coordinate as the tape interpreter keeps it: its own limbs and the three combinations with the other
 // coordinate that the point formulas read (ecm.c:407-457 split into X and Z halves as in gecm_quad.hpp), all made
 // ONCE when the point is created, from one exchange between the X row and the Z row.  The exchange goes through
@@ -355,17 +402,285 @@ __device__ __forceinline__ void run_tape_row(const uint32_t *__restrict__ tape, 
     }
 }
 
+// ==== experiment kept for the record (round 3; off unless GECM_ROW_LDS_VARIANT is defined: tools/ab build) ============
+// Measured slower than the DPP kernel above by 3-4 % at 415, 623 and 831 bits and equal at 1023 (4096 curves,
+// profiles/r03/rowp_lds_prefetch_ab_4096_curves.txt, profiles/r03/ab_tape_and_lds_variants.txt): DESIGN.md §5c.
+#ifndef GECM_ROW_WG_WAVES
+#define GECM_ROW_WG_WAVES 4
+#endif
+#ifdef GECM_ROW_LDS_VARIANT
+// The op tape, read two events ahead through the vector memory path: a buffer load with a wave-uniform offset is
+// counted by vmcnt, which nothing else in the loop uses, so it is requested at the top of an event and waited for at its
+// end, for free.  (A scalar load shares lgkmcnt with the LDS requests and returns out of order: with one in flight
+// every LDS wait of the event would have to drain the whole queue, the operand limbs requested for later included.)
+struct TapeAhead {
+#ifndef GECM_ROW_TAPE_SMEM
+    __amdgpu_buffer_rsrc_t rsrc;
+    uint32_t len;
+    uint32_t pend;        // the word holding the byte requested last
+    __device__ __forceinline__ void open(const uint32_t *tape, uint32_t tape_len)
+    {
+        len = tape_len;
+        rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)tape, 0, (int)((tape_len + 3u) & ~3u), 0x00020000);
+        pend = 0;
+    }
+    __device__ __forceinline__ void request(uint32_t pc) { pend = __builtin_amdgcn_raw_buffer_load_b32(rsrc, 0, (int)(pc & ~3u), 0); }
+    __device__ __forceinline__ uint32_t take(uint32_t pc) const      // the byte at pc (the one requested), NOP past the end
+    {
+        const uint32_t b = __builtin_amdgcn_readfirstlane((pend >> ((pc & 3u) * 8u)) & 0xffu);
+        return pc < len ? b : GECM_OP_NOP;
+    }
+#else   // A/B: the scalar load of rounds 1-2, issued when the byte is taken
+    const uint32_t *tp;
+    uint32_t len;
+    __device__ __forceinline__ void open(const uint32_t *tape, uint32_t tape_len) { tp = tape; len = tape_len; }
+    __device__ __forceinline__ void request(uint32_t) {}
+    __device__ __forceinline__ uint32_t take(uint32_t pc) const
+    {
+        if (pc >= len) return GECM_OP_NOP;
+        const uint32_t w = tp[pc >> 2];
+        return __builtin_amdgcn_readfirstlane((w >> ((pc & 3u) * 8u)) & 0xffu);
+    }
+#endif
+};
+
+// ---- the LDS-prefetch variant (BC = 2) ----------------------------------------------------------------------------
+// In a multiply a*b/R' the limbs of ONE operand have to reach all 16 lanes of the row: 16 v_mov_b32_dpp per multiply,
+// a sixth of its VALU instructions, in a kernel that is bound by VALU issue.  Two of the three
+// multiplies of a point addition have an operand that is OLD when the multiply starts:
+//   level 1  (x_B -+ z_B)(x_A +- z_A): one of A, B is the point the previous step made, the other is older;
+//   level 3  (U +- V)^2 * (z_C | x_C): C is two steps old.
+// (The product is the same integer whichever operand is scanned, and so is everything computed from it.)  Those
+// operands are therefore taken from LDS: when a point is made, the three forms the formulas read it in (sd, ds, oth,
+// times 4) go to a slot of LDS — one ds_write per form, LDS pipe — and the multiply that needs one as its broadcast
+// operand reads it back with ds_read_b128, every lane of the row reading the same 16 bytes (a broadcast, no bank
+// conflict), requested ONE MULTIPLY AHEAD so that nothing waits for it.  The squaring in the middle (both operands
+// fresh) and the 14 % of tape events outside the rule-3 loop keep the DPP multiply.
+// tools/lds_bcast_ubench.hip (profiles/r03/lds_bcast_ubench_gfx950.txt): a 16-row body costs 900 cycles per wavefront
+// at two wavefronts per SIMD with the DPP broadcast, 700 with the limbs in registers, 824 with the four reads, their
+// wait and 16 register copies this kernel does not need.
+// LDS holds, per DPP row of the workgroup, GECM_ROW_SLOTS point slots of 3 forms of 16*NQ limbs; a slot is written
+// when its point is made and never changed; A, B, C name slots (wave-uniform numbers) as they name registers.
+#ifndef GECM_ROW_WG_WAVES
+#define GECM_ROW_WG_WAVES 4
+#endif
+#define GECM_ROW_SLOTS 5
+#define GECM_ROW_WG_ROWS (4 * GECM_ROW_WG_WAVES)
+template <int NQ>
+struct RowSlots {
+    int32_t f[GECM_ROW_SLOTS][3][16 * NQ];      // [slot][sd, ds, oth][limb]: one DPP row's points
+};
+
+template <int NQ>
+__device__ __forceinline__ void lds_put_forms(RowSlots<NQ> *L, uint32_t slot, uint32_t l, const PtR<NQ> &p)
+{
+#pragma unroll
+    for (int t = 0; t < NQ; t++) {
+        L->f[slot][0][NQ * l + t] = (int32_t)((uint32_t)p.sd.v[t] << 2);
+        L->f[slot][1][NQ * l + t] = (int32_t)((uint32_t)p.ds.v[t] << 2);
+        L->f[slot][2][NQ * l + t] = (int32_t)((uint32_t)p.oth.v[t] << 2);
+    }
+}
+
+// the first ROWS limbs of one form into every lane: ceil(ROWS/4) reads of 16 bytes at the same address in all lanes
+template <int NQ, int ROWS>
+__device__ __forceinline__ void lds_get_form(int32_t (&Ab)[ROWS], const RowSlots<NQ> *L, uint32_t slot, uint32_t form)
+{
+    typedef int32_t v4 __attribute__((ext_vector_type(4)));
+    const v4 *src = reinterpret_cast<const v4 *>(&L->f[slot][form][0]);
+    constexpr int N4 = (ROWS + 3) / 4;
+#pragma unroll
+    for (int k = 0; k < N4; k++) {
+        const v4 v = src[k];
+        if (4 * k + 0 < ROWS) Ab[4 * k + 0] = v.x;
+        if (4 * k + 1 < ROWS) Ab[4 * k + 1] = v.y;
+        if (4 * k + 2 < ROWS) Ab[4 * k + 2] = v.z;
+        if (4 * k + 3 < ROWS) Ab[4 * k + 3] = v.w;
+    }
+}
+
+// two slots none of A, B, C names (five slots, at most three in use)
+__device__ __forceinline__ void free_slots(uint32_t sA, uint32_t sB, uint32_t sC, uint32_t &f0, uint32_t &f1)
+{
+    uint32_t mask = ~((1u << sA) | (1u << sB) | (1u << sC)) & ((1u << GECM_ROW_SLOTS) - 1u);
+    f0 = (uint32_t)__builtin_ctz(mask);
+    mask &= mask - 1u;
+    f1 = (uint32_t)__builtin_ctz(mask);
+}
+
+template <int NQ, int ROWS>
+__device__ __forceinline__ void run_tape_row_lds(const uint32_t *__restrict__ tape, uint32_t tape_len, PtR<NQ> &A,
+                                                 const FeR<NQ> &s4, bool isZ, const RowSign &g, const RowMod<NQ> &m,
+                                                 RowSlots<NQ> *L, uint32_t l)
+{
+    PtR<NQ> B = A, C = A;
+    uint32_t sA = 0, sB = 0, sC = 0;
+    lds_put_forms<NQ>(L, 0, l, A);
+    auto is_fast = [](uint32_t op) { return (op & ~GECM_OP_SWAP) == (GECM_OP_STEP | GECM_OP_RULE3); };
+    TapeAhead rd;
+    rd.open(tape, tape_len);
+    rd.request(0);
+    uint32_t op = rd.take(0);
+    rd.request(1);
+    uint32_t nxt = rd.take(1);
+    uint32_t pc = 0;
+    while (pc < tape_len) {
+        if (is_fast(op)) {
+            // T = B + A (C); (B, T, C) <- (T, C, B), after the optional exchange of A and B (ecm.c:617-630, 683-713).
+            // Level 1's scanned operand is the OLDER of the two points: the A of before the exchange — its ds form if
+            // the exchange happens (it is B then), its sd form if not.
+            int32_t Ab1[ROWS], Ab3[ROWS];
+            lds_get_form<NQ, ROWS>(Ab1, L, sA, (op & GECM_OP_SWAP) ? 1u : 0u);
+            do {
+                rd.request(pc + 2);
+                const bool sw = (op & GECM_OP_SWAP) != 0;
+                if (sw) {
+                    PtR<NQ> t = A;
+                    A = B;
+                    B = t;
+                    const uint32_t ts = sA;
+                    sA = sB;
+                    sB = ts;
+                }
+                lds_get_form<NQ, ROWS>(Ab3, L, sC, 2u);              // level 3's operand, two multiplies ahead
+                __builtin_amdgcn_sched_barrier(0);
+                FeR<NQ> b1, w, t, e;
+#pragma unroll
+                for (int i = 0; i < NQ; i++) b1.v[i] = sw ? A.sd.v[i] : B.ds.v[i];
+                fer_mul_pre<NQ, ROWS, true>(w, Ab1, b1, m);          // X: U      Z: V
+                fer_other<NQ>(t, w);
+                fer_sum_diff<NQ>(e, t, w, g);                        // X: V + U  Z: U - V
+                __builtin_amdgcn_sched_barrier(0);
+                // the next step's level-1 operand: A stays where it is, the form follows that step's exchange.
+                // Requested whatever the next tape byte is (a branch here would leave the number of LDS requests in
+                // flight unknown to the compiler's wait placement, which then waits for all of them at once).
+                lds_get_form<NQ, ROWS>(Ab1, L, sA, (nxt & GECM_OP_SWAP) ? 1u : 0u);
+                __builtin_amdgcn_sched_barrier(0);
+                fer_mul<NQ, ROWS, true, false>(e, e, e, m);
+                PtR<NQ> T;
+                fer_mul_pre<NQ, ROWS, true>(T.own, Ab3, e, m);
+                row_forms<NQ>(T, g);
+                uint32_t f0, f1;
+                free_slots(sA, sB, sC, f0, f1);
+                lds_put_forms<NQ>(L, f0, l, T);
+                C = B;
+                sC = sB;
+                B = T;
+                sB = f0;
+                pc++;
+                op = nxt;
+                nxt = rd.take(pc + 1);
+            } while (is_fast(op));
+            continue;
+        }
+        rd.request(pc + 2);
+        if (op != GECM_OP_NOP) {
+            const uint32_t rule = op & GECM_OP_RULE_MASK;
+            const bool is_step = op >= GECM_OP_STEP;
+            const bool do_add = op != GECM_OP_PRAC_BEGIN;
+            const bool do_dup = op != GECM_OP_PRAC_END;
+            if (is_step && (op & GECM_OP_SWAP)) {
+                PtR<NQ> t = A;
+                A = B;
+                B = t;
+                const uint32_t ts = sA;
+                sA = sB;
+                sB = ts;
+            }
+            if (is_step && rule == GECM_OP_RULE5) {
+                PtR<NQ> t = B;
+                B = C;
+                C = t;
+                const uint32_t ts = sB;
+                sB = sC;
+                sC = ts;
+            } else if (is_step && rule == GECM_OP_RULE9) {
+                PtR<NQ> t = A;
+                A = B;
+                B = C;
+                C = t;
+                const uint32_t ts = sA;
+                sA = sB;
+                sB = sC;
+                sC = ts;
+            } else if (op == GECM_OP_PRAC_BEGIN) {
+                B = A;
+                C = A;
+                sB = sA;
+                sC = sA;
+            }
+            PtR<NQ> T, D;
+            uint32_t sT, sD;
+            free_slots(sA, sB, sC, sT, sD);
+            if (do_add) {
+                row_add<NQ, ROWS, false>(T, B.ds, A.sd, C.oth, isZ, g, m);
+                lds_put_forms<NQ>(L, sT, l, T);
+            }
+            if (do_dup) {
+                row_dup<NQ, ROWS, false>(D, A.sd, s4, isZ, g, m);
+                lds_put_forms<NQ>(L, sD, l, D);
+            }
+            if (op == GECM_OP_PRAC_END) {
+                A = T;
+                sA = sT;
+            } else if (op == GECM_OP_PRAC_BEGIN) {
+                A = D;
+                sA = sD;
+            } else if (rule == GECM_OP_RULE4) {
+                B = T;
+                sB = sT;
+                A = D;
+                sA = sD;
+            } else if (rule == GECM_OP_RULE5) {
+                PtR<NQ> t = C;
+                const uint32_t ts = sC;
+                C = T;
+                sC = sT;
+                B = t;
+                sB = ts;
+                A = D;
+                sA = sD;
+            } else {
+                PtR<NQ> oldA = C;
+                const uint32_t so = sC;
+                C = T;
+                sC = sT;
+                B = D;
+                sB = sD;
+                A = oldA;
+                sA = so;
+            }
+        }
+        pc++;
+        op = nxt;
+        nxt = rd.take(pc + 1);
+    }
+}
+
+#endif   // GECM_ROW_LDS_VARIANT
+
 // Constants of the row kernel, one array of GECM_ROW_WORDS words per kind, limb j at word j (zero padded):
 //   [0] N' = m*N, = -1 mod 2^28      [1] N      [2] c_in = R'^2 / R mod N (entry conversion: x R -> x R')
 //   [3] R mod N (exit conversion)    [4] K' of N (bias that makes the exit value's limbs non-negative)
 // (GECM_ROW_WORDS, GECM_ROW_KINDS: gecm_rowk.h)
 
 // The whole stage-1 kernel body for one lane.  nl = limbs per residue in the device buffers (R = 2^(28*nl)).
-template <int NQ, int ROWS, bool ALDS>
+// BC: how the scanned operand of a multiply reaches the lanes of its row — 0: DPP row_newbcast in the rows' wait
+// states; 1: ds_swizzle, all requested at the top of the multiply (3 or more wavefronts per SIMD); 2: from LDS, read one
+// multiply ahead, in the two multiplies of a point addition whose operand is old (run_tape_row_lds; `slots` = this
+// workgroup's LDS, otherwise unused).
+template <int NQ, int ROWS, int BC>
 __device__ __forceinline__ void stage1_row(const uint32_t *__restrict__ tape, uint32_t tape_len, uint32_t *__restrict__ X,
                                            uint32_t *__restrict__ Z, const uint32_t *__restrict__ S, size_t stride,
-                                           uint32_t nl, const uint32_t *__restrict__ rc, uint32_t rho_n)
+                                           uint32_t nl, const uint32_t *__restrict__ rc, uint32_t rho_n,
+                                           void *slots_ = nullptr)
 {
+#ifdef GECM_ROW_LDS_VARIANT
+    RowSlots<NQ> *slots = static_cast<RowSlots<NQ> *>(slots_);
+#else
+    (void)slots_;
+#endif
+    constexpr bool ALDS = BC == 1;
     const uint32_t cidx = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;      // wavefronts of a workgroup are independent
     const uint32_t l = threadIdx.x & 15u;
     const bool isZ = (threadIdx.x & 16u) != 0;
@@ -395,7 +710,11 @@ __device__ __forceinline__ void stage1_row(const uint32_t *__restrict__ tape, ui
     row_forms<NQ>(P, g);
     fer_load<NQ>(t, S, stride, cidx, l, nl);
     fer_mul<NQ, ROWS, true, ALDS>(s4, t, cin, mp);
-    run_tape_row<NQ, ROWS, ALDS>(tape, tape_len, P, s4, isZ, g, mp);
+#ifdef GECM_ROW_LDS_VARIANT
+    if constexpr (BC == 2) run_tape_row_lds<NQ, ROWS>(tape, tape_len, P, s4, isZ, g, mp, slots + (threadIdx.x >> 4), l);
+    else
+#endif
+        run_tape_row<NQ, ROWS, ALDS>(tape, tape_len, P, s4, isZ, g, mp);
     fer_mul<NQ, ROWS, false, ALDS>(t, P.own, one, mn);                    // x*R' -> x*R (mod N), in (-N/16, 17N/16)
     // + K' (a multiple of N with every limb >= 2^28 - 1): all limbs positive; then one carry-save pass
     uint32_t u[NQ];

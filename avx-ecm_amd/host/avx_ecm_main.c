@@ -110,6 +110,7 @@ typedef struct {
     const gecm_pairs *pm;      /* the pair map of the current prime range (made once, shared) */
     first_range_t *fr;         /* stage 1: the first range's map, being made on the pass thread meanwhile (or NULL) */
     double kernel_ms;
+    int progress;              /* print the launches of a long stage 1 as they finish (GPU 0 of a pass that prints live) */
 } job_t;
 
 typedef struct {
@@ -213,6 +214,15 @@ static void *job_stage1(void *p)
             pthread_mutex_unlock(&fr->mu);
             if (fr->valid)
                 (void)gecm_stage2_pair_prepare(j->ctx, fr->D, fr->U, fr->pm.steps, fr->pm.pairmap_v, fr->pm.pairmap_u, fr->pm.amin);
+        }
+        if (j->rc == 0 && j->progress) {
+            /* a 1e8 prime range is 13 launches of up to minutes each: say where it is (the reference prints
+             * "accumulating prime" every 8192 primes, ecm.c:1834-1842) */
+            uint32_t done = 0, total = 0, shown = 0;
+            while (gecm_stage1_progress(j->ctx, &done, &total) == 0 && total > 1 && done < total) {
+                if (done != shown) { printf("stage 1, range %u: launch %u of %u done\r", j->range, done, total); fflush(stdout); shown = done; }
+                usleep(200000);
+            }
         }
         if (j->rc == 0) j->rc = gecm_sync(j->ctx);
         if (j->rc == 0) j->kernel_ms += gecm_last_kernel_ms(j->ctx);
@@ -459,7 +469,7 @@ static void *pass_run(void *arg)
         if (r > 0 || R->nranges > 1)
             plog(ps, "Found %lu primes in range [%lu : %lu]\n", (unsigned long)rd.nprimes, (unsigned long)rd.lo, (unsigned long)rd.hi);   /* ecm.c:1228 */
         plog(ps, "Commencing Stage 1 @ prime %lu\n", (unsigned long)rd.first_prime);               /* ecm.c:1233 */
-        for (int g = 0; g < G; g++) { ps->jobs[g].B1 = R->B1; ps->jobs[g].range = (uint32_t)r; }
+        for (int g = 0; g < G; g++) { ps->jobs[g].B1 = R->B1; ps->jobs[g].range = (uint32_t)r; ps->jobs[g].progress = ps->live && g == 0; }
         int make_map = 0;
         first_range_t *fr = NULL;
         if (R->do_stage2 && r == R->nranges - 1) {

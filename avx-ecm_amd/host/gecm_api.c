@@ -910,6 +910,19 @@ int gecm_get_lanes_per_curve(const gecm_ctx *c)
     return gecm_dev_last_lanes(c->last_on_f ? c->dev_f : c->dev);
 }
 
+int gecm_stage1_progress(const gecm_ctx *c, uint32_t *done, uint32_t *total)
+{
+    if (!c) return GECM_ERR_ARG;
+    return gecm_dev_stage1_progress(c->last_on_f ? c->dev_f : c->dev, done, total) ? GECM_ERR_DEVICE : GECM_OK;
+}
+
+int gecm_last_kernel_name(const gecm_ctx *c, char *buf, size_t len)
+{
+    if (!c || !buf || !len) return GECM_ERR_ARG;
+    snprintf(buf, len, "%s", gecm_dev_last_kernel(c->last_on_f ? c->dev_f : c->dev));
+    return GECM_OK;
+}
+
 int gecm_sync(gecm_ctx *c)
 {
     if (!c) return GECM_ERR_ARG;

@@ -99,6 +99,9 @@ class RangeDesc(ctypes.Structure):
                 ("checkpoint", c_int)]
 
 
+_sig("gecm_last_kernel_name", c_int, c_void_p, c_char_p, c_size_t)
+_sig("gecm_stage1_progress", c_int, c_void_p, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32))
+EXPORTS += ["gecm_last_kernel_name", "gecm_stage1_progress"]
 _sig("gecm_stage1_ranges", c_int, c_u64)
 _sig("gecm_stage1_range", c_int, c_void_p, c_u64, ctypes.c_uint32)
 _sig("gecm_stage1_describe_range", c_int, c_u64, c_u64, ctypes.c_uint32, ctypes.POINTER(RangeDesc))
@@ -265,6 +268,17 @@ class Engine:
     def lanes_per_curve(self):
         """what the last stage-1 launch used"""
         return _chk(lib.gecm_get_lanes_per_curve(self._h), "gecm_get_lanes_per_curve")
+
+    def stage1_progress(self):
+        """(launches finished, launches made) of the stage-1 call in flight"""
+        d, t = ctypes.c_uint32(0), ctypes.c_uint32(0)
+        _chk(lib.gecm_stage1_progress(self._h, ctypes.byref(d), ctypes.byref(t)), "gecm_stage1_progress")
+        return d.value, t.value
+
+    def last_kernel_name(self):
+        buf = ctypes.create_string_buffer(128)
+        _chk(lib.gecm_last_kernel_name(self._h, buf, len(buf)), "gecm_last_kernel_name")
+        return buf.value.decode()
 
     def last_kernel_ms(self):
         return lib.gecm_last_kernel_ms(self._h)

@@ -335,7 +335,7 @@ def main():
     st = eng.stage1_stats()
     cfg = eng.cfg
     lanes = eng.lanes_per_curve()
-    kname = kernel_name(lanes, cfg.dev_limbs)
+    kname = kernel_name(lanes, cfg.dev_limbs) if a.no_engine else eng.last_kernel_name()
 
     # what every rank did, gathered so that the line checks itself: the world size as the process group reports it,
     # each rank's curve range, device and kernel time

@@ -165,6 +165,13 @@ int gecm_set_lanes_per_curve(gecm_ctx *ctx, int lanes);
 int gecm_set_special_form(gecm_ctx *ctx, int on);
 int gecm_get_special_form(const gecm_ctx *ctx, int *k, int *limbs);
 int gecm_get_lanes_per_curve(const gecm_ctx *ctx);
+/* Progress of the stage-1 call in flight: a long op tape (200 MB for a 1e8 prime range) runs as several kernel launches,
+ * cut between two prac() calls; *done of *total have finished.  Callable from the launching thread between
+ * gecm_stage1 / gecm_stage1_range and gecm_sync (the reference prints "accumulating prime" every 8192 primes). */
+int gecm_stage1_progress(const gecm_ctx *ctx, uint32_t *done, uint32_t *total);
+/* the stage-1 kernel the last launch ran, by the name rocprofv3 prints for it ("k_stage1_rowp<1, 16>", "k_stage1<15>"):
+ * what a profile of the run has to be matched against */
+int gecm_last_kernel_name(const gecm_ctx *ctx, char *buf, size_t len);
 /* milliseconds of the last stage-1 kernel, from HIP events on the context's stream */
 double gecm_last_kernel_ms(const gecm_ctx *ctx);
 
