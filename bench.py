@@ -111,10 +111,15 @@ def cpu_baseline(n, b1, budget_s=30.0):
                    "sample": "oracle/_ref/avx-ecm-52 N 8 %d 1 %d 1000: 8 curves, 1 thread, %.2f s stage 1" % (b1, b1, t1)}
             left = budget_s - (time.perf_counter() - t_start)
             if ncores > 1 and t1 * 2.0 < left:
-                tn = run(ncores, max(20.0, 4 * t1))
+                tns = [run(ncores, max(20.0, 4 * t1))]
+                while len(tns) < 3 and budget_s - (time.perf_counter() - t_start) > 1.5 * tns[-1]:
+                    tns.append(run(ncores, max(20.0, 4 * t1)))       # more samples while the budget lasts
+                tn = sorted(tns)[len(tns) // 2]
                 out = {"value": 8 * ncores / tn, "unit": "curves/s", "cores": ncores, "kind": "reference",
-                       "sample": "oracle/_ref/avx-ecm-52 N %d %d %d %d 1000: %d curves on %d threads, %.2f s stage 1; "
-                                 "1 thread: %.3f curves/s" % (8 * ncores, b1, ncores, b1, 8 * ncores, ncores, tn, 8 / t1)}
+                       "sample": "oracle/_ref/avx-ecm-52 N %d %d %d %d 1000: %d curves on %d threads, median of %d runs "
+                                 "(%s s of stage 1); 1 thread, 8 curves: %.3f curves/s"
+                                 % (8 * ncores, b1, ncores, b1, 8 * ncores, ncores, len(tns), ", ".join("%.2f" % t for t in tns), 8 / t1),
+                       "samples_curves_per_s": [8 * ncores / t for t in tns]}
         except Exception as e:  # SIGILL on a host without AVX-512, missing libgmp, time-out, ...
             if out is None:
                 sys.stderr.write("bench: reference binary unusable here (%s); timing the scalar port\n" % e)
@@ -379,16 +384,19 @@ def main():
         # were taken on THIS build: the file carries the source hashes gecm_version() reports (the kernels' K/R/D parts)
         traffic = valu_per_mad = valu_active = None
         build = "" if a.no_engine else pyecm.lib.gecm_version().decode()
-        build_dev = " ".join(f for f in build.split() if f[:2] in ("K:", "R:", "D:"))
+        # the part of the build that makes this kernel's code: R (the 32-lane kernels' sources) or K (the others')
+        part = "R:" if kname.startswith("k_stage1_row") else "K:"
+        pick = lambda b: " ".join(f for f in (b or "").split() if f[:2] == part)
+        build_dev = pick(build)
         pmc_state = "no profiles/pmc_latest.json"
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
             if pm.get("kernel") != kname or pm.get("curves") != a.curves or pm.get("B1") != a.b1:
                 pmc_state = "committed profile is of another workload (%s, %s curves, B1 %s)" % (pm.get("kernel"), pm.get("curves"), pm.get("B1"))
-            elif pm.get("build") != build_dev:
-                pmc_state = "committed profile was taken on another build (%s), this is %s" % (pm.get("build"), build_dev)
+            elif pick(pm.get("build")) != build_dev:
+                pmc_state = "committed profile was taken on another build of this kernel (%s), this is %s" % (pick(pm.get("build")), build_dev)
             else:
-                pmc_state = "profiles/pmc_latest.json, same build"
+                pmc_state = "profiles/pmc_latest.json, same kernel sources (%s)" % build_dev
                 traffic = pm["hbm_bytes_per_launch_corrected"]
                 waves = pm["counters"]["SQ_WAVES"]
                 valu_per_mad = pm["valu_insts_per_wave"] * waves / (mads * a.curves / 64.0)
