@@ -695,35 +695,50 @@ int main(int argc, char **argv)
     /* two sets of contexts when there is more than one pass to overlap (one prime range only: with several, a pass
      * takes minutes to hours and its checkpoints are written as it goes) */
     const int slots = (npasses > 1 && R.nranges == 1 && !getenv("GECM_NO_PIPELINE")) ? 2 : 1;
+    /* Special-form inputs for which the reference leaves REDC (main.c:505-527, 642-684): it then works modulo
+     * Mw = 2^k - 1, 2^k + 1 or 2^k - c throughout, curve construction included, and keeps the number given for the "N="
+     * of its files and for its factor checks (ecm.c:1111-1118).  Same here: the contexts are made on Mw and report
+     * against N (gecm_set_report_modulus); the files come out as the reference's, byte for byte. */
+    static char mwdec[MPL_MAXL * 10 + 16];
+    const char *modulus = ndec;
+    if (inf.ref_special_reduction) {
+        mpl_t mw, t;
+        mpl_set_u64(&mw, 1);
+        mpl_shl(&mw, &mw, (unsigned)inf.k);
+        if (inf.form < 0) { mpl_set_u64(&t, 1); mpl_add(&mw, &mw, &t); }
+        else { mpl_set_u64(&t, inf.form > 1 ? (uint64_t)inf.c : 1); mpl_sub(&mw, &mw, &t); }
+        mpl_get_dec(mwdec, &mw);
+        modulus = mwdec;
+    }
     static gecm_ctx *ctx[2][MAX_GPUS];
     for (int s = 0; s < slots; s++)
-        for (int g = 0; g < gpus; g++)
-            if (gecm_create(&ctx[s][g], g % devices, ndec, 52)) { fprintf(stderr, "%s\n", gecm_last_error()); return 2; }
+        for (int g = 0; g < gpus; g++) {
+            if (gecm_create(&ctx[s][g], g % devices, modulus, 52)) { fprintf(stderr, "%s\n", gecm_last_error()); return 2; }
+            if (inf.ref_special_reduction && gecm_set_report_modulus(ctx[s][g], ndec)) { fprintf(stderr, "%s\n", gecm_last_error()); return 2; }
+        }
     gecm_config cfg;
     gecm_get_config(ctx[0][0], &cfg);
     char devname[256];
     gecm_device_name(ctx[0][0], devname, sizeof devname);
     /* main.c:529-533, verbatim: DIGITBITS and VECLEN describe the vector format at the boundary (curves come in
-     * groups of 8, limbs of 52 bits); the device's own numbers follow on a line of their own */
+     * groups of 8, limbs of 52 bits); the device's own numbers follow on a line of their own.  For a special-form run
+     * the "input size" is k, the size of 2^k -/+ c (main.c:465-483 on size_n = k). */
     printf("ECM has been configured with DIGITBITS = %d, VECLEN = %d, GMP_LIMB_BITS = %d\n", cfg.digitbits, VECLEN, 64);
     printf("Choosing MAXBITS = %d, NWORDS = %d, NBLOCKS = %d based on input size %d\n", cfg.maxbits, cfg.nwords,
-           cfg.nwords / 4, cfg.nbits);
+           cfg.nwords / 4, inf.ref_special_reduction ? inf.k : cfg.nbits);
     printf("%s: %d GPU(s) [%s], residues of %d limbs x 28 bits on the device\n", gecm_version(), gpus, devname,
            cfg.dev_limbs);
-    if (inf.ref_special_reduction) {
-        /* main.c:644-670 prints "Using special Mersenne mod for factor of: 2^k-1" here */
+    if (argc > 6) printf("starting with sigma = %lu\n", (unsigned long)R.sigma0);  /* main.c:558 */
+    printf("Input has %d bits, using %d threads (%d curves/thread)\n", inf.ref_special_reduction ? inf.nbits : cfg.nbits,
+           R.threads, (int)R.per_thread);                                          /* main.c:591-592 */
+    printf("Processing in batches of %u primes\n", 100000000u);                   /* main.c:593 */
+    if (inf.ref_special_reduction) {                                               /* main.c:644-670 */
+        if (inf.form > 1) printf("Using special pseudo-Mersenne mod for factor of: 2^%d-%d\n", inf.k, inf.form);
+        else printf("Using special Mersenne mod for factor of: 2^%d%c1\n", inf.k, inf.form > 0 ? '-' : '+');
         int fk = 0, fl = 0;
         if (gecm_get_special_form(ctx[0][0], &fk, &fl) >= 1)
-            printf("REDC modulo 2^%d%c1 (%d limbs, special reduction) serves stage 1 of this factor of 2^%d%c1 when the "
-                   "batch is large enough for it; residues are reduced modulo N\n", abs(fk), fk > 0 ? '-' : '+', fl,
-                   abs(fk), fk > 0 ? '-' : '+');
-        else
-            printf("Input divides 2^%d %c %d: running REDC on the %d-bit cofactor (residues = the reference's modulo N)\n",
-                   inf.k, inf.form > 0 ? '-' : '+', inf.form, inf.nbits);
+            printf("(batches that fill the GPU multiply modulo it with a special reduction, %d limbs; smaller ones by REDC)\n", fl);
     }
-    if (argc > 6) printf("starting with sigma = %lu\n", (unsigned long)R.sigma0);  /* main.c:558 */
-    printf("Input has %d bits, using %d threads (%d curves/thread)\n", cfg.nbits, R.threads, (int)R.per_thread);   /* main.c:591-592 */
-    printf("Processing in batches of %u primes\n", 100000000u);                   /* main.c:593 */
     printf("Initialization took %1.4f seconds.\n", now() - R.t_start);             /* main.c:776 */
     fflush(stdout);
 

@@ -63,6 +63,8 @@ int gecm_device_count(void) { return gecm_dev_count(); }
 struct gecm_ctx {
     int device, digitbits, nwords, maxbits, nbits, nl;
     mpl_t N;
+    mpl_t N_report;      /* gecm_set_report_modulus: the number the save lines name and factors are looked for in */
+    int have_report;
     mpl_t rref_mod_n;    /* 2^(digitbits*nwords) mod N  = the reference's "one" */
     mpl_t rint_mod_n;    /* 2^(28*nl) mod N */
     mpl_t ref_to_int;    /* Rint * Rref^-1 mod N : x*Rref -> x*Rint by plain modular multiply */
@@ -365,6 +367,31 @@ void gecm_destroy(gecm_ctx *c)
     free(c->r3_28);
     free(c->n28);
     free(c);
+}
+
+/* The reference's special-form runs (main.c:505-527, 642-684) work modulo Mw = 2^k -/+ 1 or 2^k - c — curve construction,
+ * stage 1, stage 2 — while the number given, N | Mw, stays the one its files name and its factor checks use
+ * (ecm.c:1111-1118: gmpn = vnhat).  A context on Mw with N as its report modulus writes those files byte for byte. */
+int gecm_set_report_modulus(gecm_ctx *c, const char *n_str)
+{
+    if (!c) return GECM_ERR_ARG;
+    if (!n_str) { c->have_report = 0; return GECM_OK; }
+    mpl_t r, m;
+    if (mpl_set_str(&r, n_str) || mpl_cmp_u64(&r, 1) <= 0) { set_err("gecm_set_report_modulus: bad number"); return GECM_ERR_ARG; }
+    mpl_mod(&m, &c->N, &r);
+    if (!mpl_is_zero(&m)) { set_err("gecm_set_report_modulus: the number must divide the context's modulus"); return GECM_ERR_ARG; }
+    c->N_report = r;
+    c->have_report = 1;
+    c->scan_valid[0] = c->scan_valid[1] = 0;
+    return GECM_OK;
+}
+
+static const mpl_t *report_n(const gecm_ctx *c) { return c->have_report ? &c->N_report : &c->N; }
+
+/* g = gcd(value, context modulus) -> the factor of the report modulus it holds */
+static void to_report(const gecm_ctx *c, mpl_t *g)
+{
+    if (c->have_report && !mpl_is_zero(g)) { mpl_t t = *g; mpl_gcd(g, &t, &c->N_report); }
 }
 
 int gecm_get_config(const gecm_ctx *c, gecm_config *cfg)
@@ -1001,7 +1028,7 @@ int gecm_format_resume_line(gecm_ctx *c, size_t k, uint64_t b1_label, char *buf,
     if (rc) return rc;
     static __thread char hn[MPL_MAXL * 10 + 2], hxs[MPL_MAXL * 10 + 2], hzs[MPL_MAXL * 10 + 2];
     mpl_t v;
-    mpl_get_hex(hn, &c->N);
+    mpl_get_hex(hn, report_n(c));
     mpl_from_limbs32(&v, c->hx + k, c->batch, c->nl, LIMB_BITS);
     mpl_get_hex(hxs, &v);
     mpl_from_limbs32(&v, c->hz + k, c->batch, c->nl, LIMB_BITS);
@@ -1028,7 +1055,8 @@ int gecm_stage1_factor(gecm_ctx *c, size_t k, char *dec, size_t declen, int *is_
         mpl_from_limbs32(&z, c->hz + k, c->batch, c->nl, LIMB_BITS);
         mpl_gcd(&g, &z, &c->N);
     }
-    if (mpl_cmp_u64(&g, 1) > 0 && mpl_cmp(&g, &c->N) != 0) {
+    to_report(c, &g);
+    if (mpl_cmp_u64(&g, 1) > 0 && mpl_cmp(&g, report_n(c)) != 0) {
         static __thread char tmp[MPL_MAXL * 10 + 16];
         int n = mpl_get_dec(tmp, &g);
         if (dec && declen) {
@@ -1370,7 +1398,8 @@ int gecm_stage2_factor(gecm_ctx *c, size_t k, char *dec, size_t declen, int *is_
             mpl_gcd(&g, &a, &c->N);                  /* check_factor, ecm.c:2542-2557 */
         }
     }
-    if (mpl_cmp_u64(&g, 1) > 0 && mpl_cmp(&g, &c->N) != 0) {
+    to_report(c, &g);
+    if (mpl_cmp_u64(&g, 1) > 0 && mpl_cmp(&g, report_n(c)) != 0) {
         static __thread char tmp[MPL_MAXL * 10 + 16];
         int n = mpl_get_dec(tmp, &g);
         if (dec && declen) {
@@ -1408,9 +1437,29 @@ int gecm_scan_factors(gecm_ctx *c, int stage, size_t *first)
         for (size_t k = 0; k < c->batch; k++) {
             mpl_t g;
             fail_record(c, k, &g);
-            if (!mpl_is_zero(&g)) (*f)[k] = (mpl_cmp_u64(&g, 1) > 0 && mpl_cmp(&g, &c->N) != 0);
+            if (!mpl_is_zero(&g)) {
+                to_report(c, &g);
+                (*f)[k] = (mpl_cmp_u64(&g, 1) > 0 && mpl_cmp(&g, report_n(c)) != 0);
+            }
         }
     }
+    if (c->have_report)
+        /* the device looked for factors of the context's modulus: keep the curves whose gcd shares one with the
+         * report modulus (gcd(gcd(v, Mw), N) = gcd(v, N) for N | Mw) */
+        for (size_t k = 0; k < c->batch; k++)
+            if ((*f)[k]) {
+                mpl_t g;
+                mpl_from_limbs32(&g, *hg + k, c->batch, c->nl, LIMB_BITS);
+                if (mpl_is_zero(&g)) continue;            /* flagged by a failure record, settled above */
+                to_report(c, &g);
+                if (!(mpl_cmp_u64(&g, 1) > 0 && mpl_cmp(&g, report_n(c)) != 0)) {
+                    /* stage 2: the failure record decides if there is one */
+                    mpl_t fr;
+                    mpl_set_u64(&fr, 0);
+                    if (stage == 2) fail_record(c, k, &fr);
+                    if (mpl_is_zero(&fr)) (*f)[k] = 0;
+                }
+            }
     for (size_t k = 0; k < c->batch; k++)
         if ((*f)[k]) { n++; if (k < lo) lo = k; }
     c->scan_valid[stage - 1] = 1;

@@ -99,6 +99,8 @@ class RangeDesc(ctypes.Structure):
                 ("checkpoint", c_int)]
 
 
+_sig("gecm_set_report_modulus", c_int, c_void_p, c_char_p)
+EXPORTS += ["gecm_set_report_modulus"]
 _sig("gecm_last_kernel_name", c_int, c_void_p, c_char_p, c_size_t)
 _sig("gecm_stage1_progress", c_int, c_void_p, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32))
 EXPORTS += ["gecm_last_kernel_name", "gecm_stage1_progress"]
@@ -268,6 +270,11 @@ class Engine:
     def lanes_per_curve(self):
         """what the last stage-1 launch used"""
         return _chk(lib.gecm_get_lanes_per_curve(self._h), "gecm_get_lanes_per_curve")
+
+    def set_report_modulus(self, n):
+        """save lines name n and factors are reported of n (a divisor of the context's modulus): the reference's
+        special-form runs, which work modulo 2^k -/+ 1 or 2^k - c and report against the number given"""
+        _chk(lib.gecm_set_report_modulus(self._h, None if n is None else str(n).encode()), "gecm_set_report_modulus")
 
     def stage1_progress(self):
         """(launches finished, launches made) of the stage-1 call in flight"""

@@ -95,9 +95,13 @@ int gecm_upload_points(gecm_ctx *ctx, const void *X, const void *Z, const void *
  * (find_primitive_factor, main.c:187-352, 445-457).  n_dec receives the decimal N the run is made on;
  * log receives the lines the reference prints on the way ("gen: ...", "removing algebraic ...",
  * "commencing parallel ecm on ...", "Mersenne input ... determined to be faster by REDC"), byte for byte.
- * libgecm always multiplies by REDC modulo N.  When the reference would instead fold modulo 2^k -/+ c
- * (ref_special_reduction = 1; vecarith52.c:284-2436) its save lines hold residues modulo 2^k -/+ c;
- * libgecm's are those residues reduced modulo N (DESIGN.md §9 has the one exception found).           */
+ * When the reference would fold modulo Mw = 2^k -/+ 1 or 2^k - c (ref_special_reduction = 1; main.c:505-527, 642-684,
+ * vecarith52.c:284-2436) it works modulo Mw THROUGHOUT — curve construction included — and its files hold residues
+ * modulo Mw next to "N=" the number given, in which it also looks for factors (ecm.c:1111-1118).  To write those
+ * files byte for byte, create the context on Mw and name N with gecm_set_report_modulus (the command-line driver does;
+ * nine reference runs in tests/golden/special.json).  A context created on N itself gives the residues modulo N of a
+ * run modulo N — with the cheaper special-form multiply where it pays, gecm_set_special_form — which is what a
+ * caller wants who is not after the reference's bytes.                                                              */
 typedef struct {
     int form;                   /* the reference's isMersenne: 0, +1 (2^k - 1), -1 (2^k + 1), else c of 2^k - c */
     int k;
@@ -111,6 +115,11 @@ int gecm_prepare_input(const char *expr, int digitbits, char *n_dec, size_t n_le
  * mpz_sizeinbase(f, 10) = floor(bits * log10 2) + 1, which is the digit count or one more (a 12-digit
  * factor of 40 bits is labelled C13).  This returns that number for a decimal string.                 */
 int gecm_sizeinbase10(const char *dec);
+/* The number the save lines name ("N=0x...") and factors are reported of, when it is not the context's modulus but a
+ * divisor of it: the reference's gmpn = vnhat for special-form inputs (ecm.c:1111-1118).  n_str decimal or 0x-hex, must
+ * divide the modulus the context was created on; NULL restores the default.  gecm_stage1_factor, gecm_stage2_factor and
+ * gecm_scan_factors then report gcd(value, n) as the reference's check_factor(value, gmpn) does.                      */
+int gecm_set_report_modulus(gecm_ctx *ctx, const char *n_str);
 
 /* ---- L1 phase 1: stage 1 (ecm_stage1, ecm.c:1806-1854) -------------------------------------
  * P <- [prod of prime powers < B1] P for every curve of the batch.  Asynchronous: returns after

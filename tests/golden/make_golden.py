@@ -26,7 +26,9 @@ into oracle/_ref/).  The fixtures are data (inputs + outputs); no reference sour
                 curve / thread / vec with more than one thread (ecm.c:1356-1366; with a fixed sigma every
                 thread runs the same eight sigmas, ecm.c:1187)
 
-usage: python tests/golden/make_golden.py [--only stage1|l0|inputs|stage2acc|multirange|batches] [--quick]
+  special.json : special-form inputs end to end (stage 1 and stage 2): the reference works modulo 2^k -/+ 1 or 2^k - c
+
+usage: python tests/golden/make_golden.py [--only stage1|l0|inputs|stage2acc|multirange|batches|special] [--quick]
 """
 import json, os, random, re, subprocess, sys, tempfile, hashlib
 
@@ -332,6 +334,30 @@ def gen_multirange():
     json.dump(cases, open(path, "w"), indent=1)
 
 
+def gen_special():
+    """Inputs for which the reference leaves REDC (main.c:505-527, 642-684): N | 2^k - 1, N | 2^k + 1, 2^k = c (mod N).
+    It then works modulo Mw = 2^k -/+ 1 or 2^k - c throughout — curve construction included — and its files hold
+    residues modulo Mw next to N= the number given (ecm.c:1111-1118)."""
+    cof251 = (2 ** 251 - 1) // 503 // 54217
+    cases = []
+    for name, expr, b1, b2, sigma0 in (("M251_cofactor", str(cof251), 2000, 50000, 1000),
+                                       ("M251_cofactor_b1_20000_stage2", str(cof251), 20000, 1000000, 7000),
+                                       ("M499_cofactor", "(2^499-1)/20959", 2000, 50000, 1000),
+                                       ("P523_cofactor", "(2^523+1)/3", 2000, 50000, 1000),
+                                       ("pseudo_2^400-593", "2^400-593", 2000, 50000, 1000),
+                                       ("pseudo_2^64+13", "2^64+13", 500, 5000, 1000),
+                                       ("M127", "2^127-1", 1000, 20000, 1000),
+                                       ("M1009", "2^1009-1", 500, 10000, 1000),
+                                       ("F8_2^2^3+1", "2^2^3+1", 500, 5000, 1000)):
+        print("special:", name, flush=True)
+        c = run_ref(52, expr, 8, b1, b2, sigma0, keep_stdout=True)
+        c["name"] = name
+        m = re.search(r"Using special (?:pseudo-)?Mersenne mod for factor of: 2\^(\d+)([-+])(\d+)", "\n".join(c["stdout_lines"]))
+        c["special"] = {"k": int(m.group(1)), "sign": m.group(2), "c": int(m.group(3))} if m else None
+        cases.append(c)
+    json.dump(cases, open(os.path.join(HERE, "special.json"), "w"), indent=1)
+
+
 def gen_batches():
     """More curves than one reference batch (8 x threads)."""
     n415 = rand_n(415)
@@ -370,3 +396,5 @@ if __name__ == "__main__":
         gen_multirange()
     if only in (None, "batches"):
         gen_batches()
+    if only in (None, "special"):
+        gen_special()

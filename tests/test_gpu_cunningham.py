@@ -1,12 +1,14 @@
 """Cunningham-type inputs (N | 2^k -/+ 1) on the GPU.
 
 The reference strips algebraic factors and then either keeps REDC (small cofactor) or switches to
-multiplication modulo 2^k -/+ 1 (main.c:405-527).  libgecm always uses REDC modulo N:
+multiplication modulo 2^k -/+ 1 (main.c:405-527):
  * REDC case: save_b1.txt of the avx-ecm driver is byte-identical to the reference's, banner lines included;
- * special-reduction case: the reference's save lines hold residues modulo 2^k -/+ 1; ours are the same
-   residues modulo N on every lane where the reference's value is the true point [k]P (checked against an
-   independent x-only ladder, tests/xladder.py).  On the fixture the reference is wrong on one lane of
-   eight (sigma 1006); there the GPU result is checked against the independent ladder alone."""
+ * special-reduction case: the reference works modulo Mw = 2^k -/+ 1 throughout and so does the driver (contexts on Mw,
+   N as report modulus): byte-identical files (tests/test_gpu_special.py has nine such runs).  A context created on N
+   itself computes modulo N, with the special-form multiply where it pays: its residues are the TRUE point [k]P modulo N
+   on every lane (checked against an independent x-only ladder, tests/xladder.py) and equal the reference's modulo N on
+   every lane but one — sigma 1006, where the reference's curve set-up inversion fails modulo Mw (Mw has the factors
+   503 and 54217 that N has not) and it goes on with a stale operand: its point there is not [k]P."""
 import json
 import os
 import subprocess
@@ -67,19 +69,14 @@ def test_special_reduction_case_residues_equal_the_references_modulo_n():
                 assert _field(l, "X") == _field(r, "X") % n and _field(l, "Z") == _field(r, "Z") % n
 
 
-def test_driver_on_a_mersenne_cofactor_names_the_path_and_writes_residues_modulo_n():
+def test_driver_on_a_mersenne_cofactor_writes_the_references_file():
     c = RUNS["special_m251_cofactor"]
-    n = int(c["N"])
-    good = c["reference_lane_is_the_true_point"]
     with tempfile.TemporaryDirectory() as d:
         p = subprocess.run([EXE, c["N"], "8", str(c["B1"]), "1", str(c["B2"]), str(c["sigma0"])], cwd=d,
                            capture_output=True, text=True, timeout=600)
         assert p.returncode == 0, p.stdout + p.stderr
         save = open(os.path.join(d, "save_b1.txt")).read().splitlines()
     assert "removing algebraic C1 factor 0" in p.stdout                       # what the reference prints here
-    assert "REDC modulo 2^251-1 (10 limbs, special reduction) serves stage 1" in p.stdout
-    assert len(save) == 8
-    for k, (l, r) in enumerate(zip(save, c["save_lines"])):
-        assert _field(l, "N") == n and _field(l, "X") < n and _field(l, "Z") < n
-        if good[k]:
-            assert _field(l, "X") == _field(r, "X") % n and _field(l, "Z") == _field(r, "Z") % n
+    assert "Using special Mersenne mod for factor of: 2^251-1" in p.stdout    # main.c:644-670
+    assert "Choosing MAXBITS = 416, NWORDS = 8, NBLOCKS = 2 based on input size 251" in p.stdout
+    assert save == c["save_lines"]                                             # all eight lanes, modulo 2^251 - 1

@@ -217,3 +217,26 @@ def test_oracle_multirange_against_the_reference_files(orc, case):
     assert got["save"][0] == case["save_lines"][0]
     done = [l for l in case["stdout_lines"] if l.startswith("Stage 1 completed")]
     assert "prime %d with %d point-adds and %d point-doubles" % (got["save"][1][2], got["save"][1][0], got["save"][1][1]) in done[-1]
+
+
+# ---- special-form inputs: the reference works modulo 2^k -/+ 1 or 2^k - c throughout (main.c:505-527, 642-684) ----
+SPECIAL = json.load(open(os.path.join(GOLDEN, "special.json"))) if os.path.exists(os.path.join(GOLDEN, "special.json")) else []
+
+
+@pytest.mark.parametrize("case", SPECIAL, ids=[c["name"] for c in SPECIAL])
+def test_oracle_modulo_the_special_modulus_gives_the_reference_s_residues(orc, case):
+    """the reference's special-reduction run is a run modulo Mw: the oracle (generic arithmetic) on Mw writes the X and Z
+    of the reference's save lines on every lane, the ones whose curve set-up inversion fails modulo Mw included"""
+    sp = case["special"]
+    mw = (1 << sp["k"]) + (sp["c"] if sp["sign"] == "+" else -sp["c"])
+    n = int(case["save_lines"][0].split("N=0x")[1].split(";")[0], 16)
+    assert mw % n == 0
+    c = orc.orc_create(str(mw).encode(), 52)
+    assert orc.orc_nwords(c) == case["nwords"]
+    line = ctypes.create_string_buffer(16384)
+    for k, want in enumerate(case["save_lines"]):
+        orc.orc_stage1_line(c, case["sigma0"] + k, case["B1"], line, len(line), None, 0, None)
+        got = line.value.decode()
+        for key in ("X", "Z"):
+            assert got.split(key + "=0x")[1].split(";")[0] == want.split(key + "=0x")[1].split(";")[0], (case["name"], k, key)
+    orc.orc_destroy(c)
