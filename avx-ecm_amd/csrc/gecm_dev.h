@@ -30,6 +30,9 @@ int gecm_dev_open(gecm_dev **out, int device, int nl, const uint32_t *n, const u
                   const uint32_t *one, uint32_t rho);
 void gecm_dev_close(gecm_dev *d);
 int gecm_dev_device_name(gecm_dev *d, char *buf, size_t len);
+int gecm_dev_memory(gecm_dev *d, uint64_t *free_bytes, uint64_t *total_bytes);   /* hipMemGetInfo */
+/* device bytes of a batch: stage-1 arrays, plus (npb != 0) the stage-2 allocations for that table / chunk / ring size */
+uint64_t gecm_dev_batch_bytes(gecm_dev *d, size_t curves, uint32_t npb, uint32_t G, uint32_t ring_size);
 
 /* (re)allocate state for ncurves curves: X, Z, S (+ scratch for downloads) */
 int gecm_dev_resize(gecm_dev *d, size_t ncurves);

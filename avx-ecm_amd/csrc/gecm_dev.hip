@@ -217,6 +217,16 @@ extern "C" void gecm_dev_close(gecm_dev *d)
     delete d;
 }
 
+extern "C" int gecm_dev_memory(gecm_dev *d, uint64_t *free_bytes, uint64_t *total_bytes)
+{
+    HIPCHK(hipSetDevice(d->device));
+    size_t f = 0, t = 0;
+    HIPCHK(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    return 0;
+}
+
 extern "C" int gecm_dev_device_name(gecm_dev *d, char *buf, size_t len)
 {
     hipDeviceProp_t p;
@@ -568,10 +578,34 @@ extern "C" int gecm_dev_set_s2const(gecm_dev *d, const uint32_t *r3, uint32_t in
  * batch of a few thousand curves (a few dozen wavefronts) is split into K interleaved chains per curve until there
  * are 2 wavefronts per SIMD (csrc/gecm_stage2.hpp, s2_init_k / giant_chunk_k).  1 for batches that fill the chip.
  * GECM_S2_SUBSEQ=1..32 (a power of two) overrides, for measurements. */
-extern "C" uint32_t gecm_dev_s2_subseq(gecm_dev *d)
+static uint32_t s2_slices_for(const gecm_dev *d, size_t stride);
+static uint32_t s2_subseq_for(const gecm_dev *d, size_t stride);
+
+/* Device bytes a batch of `curves` curves takes: the five stage-1 arrays, and with npb != 0 the stage-2 allocations of
+ * gecm_dev_s2_init for a table of npb entries, chunks of G giant steps and a ring of ring_size (with the sub-sequence
+ * and slice counts a batch of that size gets).  The same sums as the hipMallocs below. */
+extern "C" uint64_t gecm_dev_batch_bytes(gecm_dev *d, size_t curves, uint32_t npb, uint32_t G, uint32_t ring_size)
+{
+    const size_t stride = (curves + 63) / 64 * 64;
+    const uint64_t coord = (uint64_t)d->nl * stride * sizeof(uint32_t);
+    uint64_t words = 5 + 1;                                   // X, Z, S, two scratch arrays; factor-scan gcds
+    if (npb) {
+        const uint64_t K = s2_subseq_for(d, stride), slices = s2_slices_for(d, stride);
+        words += (uint64_t)npb + 3 * GECM_S2_BLK + 2 + slices + (K > 1 ? K + 1 : 1) + (2 * ((uint64_t)G + 2) + G + ring_size);
+        if (K > 1) {
+            const uint64_t Gs = G / K + 1;
+            words += K * 3 * GECM_S2_BLK + K * (2 * (Gs + 2) + Gs) + 2;
+        }
+    }
+    return words * coord;
+}
+
+extern "C" uint32_t gecm_dev_s2_subseq(gecm_dev *d) { return s2_subseq_for(d, d->stride); }
+
+static uint32_t s2_subseq_for(const gecm_dev *d, size_t stride)
 {
     // two wavefronts per SIMD is the target (4096 curves, B2 = 1e8: K = 1 1.14 s, 4 0.75 s, 16 and 32 0.64 s)
-    const size_t waves = d->stride / 64, want = (size_t)d->cus * 4 * 2;
+    const size_t waves = stride / 64, want = (size_t)d->cus * 4 * 2;
     uint32_t k = 1;
     while (k < 32 && waves * (k * 2) <= want) k *= 2;
     if (const char *e = getenv("GECM_S2_SUBSEQ")) {
@@ -579,6 +613,18 @@ extern "C" uint32_t gecm_dev_s2_subseq(gecm_dev *d)
         if (v >= 1 && v <= 32 && (v & (v - 1)) == 0) k = (uint32_t)v;
     }
     return k;
+}
+
+static uint32_t s2_slices_for(const gecm_dev *d, size_t stride)
+{
+    const size_t waves = stride / 64, want = (size_t)d->cus * 4 * GECM_S2_WAVES_PER_SIMD;
+    size_t p = waves ? (want + waves - 1) / waves : 1;
+    uint32_t s = (uint32_t)(p < 1 ? 1 : p > GECM_S2_MAX_SLICES ? GECM_S2_MAX_SLICES : p);
+    if (const char *e = getenv("GECM_S2_SLICES")) {      // measurement knob (tools/s2_small.py)
+        const long v = strtol(e, nullptr, 10);
+        if (v >= 1 && v <= GECM_S2_MAX_SLICES) s = (uint32_t)v;
+    }
+    return s;
 }
 
 extern "C" uint32_t gecm_dev_s2_fail_planes(gecm_dev *d) { return d->s2_K > 1 ? d->s2_K + 1 : 1; }
@@ -610,15 +656,7 @@ extern "C" int gecm_dev_s2_init(gecm_dev *d, const uint32_t *keep, size_t keep_w
         // (2048 wavefronts) went from 8.26 s to 7.68 s per 1e8 range with 4 slices, 7.57 s with 8; 32,768 curves from
         // 2.04 s (8 slices) to 1.96 s (32); 4096 curves from 0.380 s (32) to 0.371 s (64)
         // (profiles/r02_stage2_slices.txt).
-        {
-            const size_t waves = d->stride / 64, want = (size_t)d->cus * 4 * GECM_S2_WAVES_PER_SIMD;
-            size_t p = waves ? (want + waves - 1) / waves : 1;
-            d->s2_slices = (uint32_t)(p < 1 ? 1 : p > GECM_S2_MAX_SLICES ? GECM_S2_MAX_SLICES : p);
-            if (const char *e = getenv("GECM_S2_SLICES")) {      // measurement knob (tools/s2_small.py)
-                const long v = strtol(e, nullptr, 10);
-                if (v >= 1 && v <= GECM_S2_MAX_SLICES) d->s2_slices = (uint32_t)v;
-            }
-        }
+        d->s2_slices = s2_slices_for(d, d->stride);
         HIPCHK(hipMalloc(&d->dAcc, coord * d->s2_slices));
         HIPCHK(hipMalloc(&d->dFail, coord * (K > 1 ? K + 1 : 1)));       // plane 0 + one per sub-sequence
         if (K > 1) {

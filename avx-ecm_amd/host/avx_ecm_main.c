@@ -685,17 +685,7 @@ int main(int argc, char **argv)
     if (!R.rd) { fprintf(stderr, "out of memory\n"); return 2; }
     R.rd_pending = pthread_create(&R.rd_thread, NULL, describe_ranges, &R) == 0;
     if (!R.rd_pending) describe_ranges(&R);
-    /* passes: as many reference batches as fit FULL_BATCH distinct curves per GPU.  GECM_PASS_CURVES (distinct curves
-     * per pass over all GPUs) overrides it for tests. */
-    size_t cap = (size_t)FULL_BATCH * (size_t)gpus;
-    if (getenv("GECM_PASS_CURVES") && atol(getenv("GECM_PASS_CURVES")) > 0) cap = (size_t)atol(getenv("GECM_PASS_CURVES"));
-    size_t batches_per_pass = cap / R.ub;
-    if (batches_per_pass < 1) batches_per_pass = 1;
-    const size_t npasses = (R.nbatches + batches_per_pass - 1) / batches_per_pass;
-    /* two sets of contexts when there is more than one pass to overlap (one prime range only: with several, a pass
-     * takes minutes to hours and its checkpoints are written as it goes) */
-    const int slots = (npasses > 1 && R.nranges == 1 && !getenv("GECM_NO_PIPELINE")) ? 2 : 1;
-    /* Special-form inputs for which the reference leaves REDC (main.c:505-527, 642-684): it then works modulo
+    /* Special-form inputs for which the reference leaves REDC    /* Special-form inputs for which the reference leaves REDC (main.c:505-527, 642-684): it then works modulo
      * Mw = 2^k - 1, 2^k + 1 or 2^k - c throughout, curve construction included, and keeps the number given for the "N="
      * of its files and for its factor checks (ecm.c:1111-1118).  Same here: the contexts are made on Mw and report
      * against N (gecm_set_report_modulus); the files come out as the reference's, byte for byte. */
@@ -711,7 +701,31 @@ int main(int argc, char **argv)
         modulus = mwdec;
     }
     static gecm_ctx *ctx[2][MAX_GPUS];
-    for (int s = 0; s < slots; s++)
+    for (int g = 0; g < gpus; g++) {
+        if (gecm_create(&ctx[0][g], g % devices, modulus, 52)) { fprintf(stderr, "%s\n", gecm_last_error()); return 2; }
+        if (inf.ref_special_reduction && gecm_set_report_modulus(ctx[0][g], ndec)) { fprintf(stderr, "%s\n", gecm_last_error()); return 2; }
+    }
+    /* passes: as many reference batches as fit FULL_BATCH distinct curves per GPU — or what the device's memory takes
+     * (the stage-2 table of 1024-bit curves is 1.1 MB per curve: 149 GB for a full batch).  GECM_PASS_CURVES (distinct
+     * curves per pass over all GPUs) overrides it for tests. */
+    uint64_t mem_free = 0, mem_total = 0;
+    (void)gecm_device_memory(ctx[0][0], &mem_free, &mem_total);
+    const uint64_t budget = mem_free / 10 * 9 / (uint64_t)per_gpu;
+    size_t fit = FULL_BATCH;
+    while (fit > 64 && mem_free && gecm_batch_bytes(ctx[0][0], fit, R.do_stage2, R.B1, 0, 0) > budget) fit = fit / 2 / 64 * 64;
+    if (fit < 64) fit = 64;
+    size_t cap = fit * (size_t)gpus;
+    if (getenv("GECM_PASS_CURVES") && atol(getenv("GECM_PASS_CURVES")) > 0) cap = (size_t)atol(getenv("GECM_PASS_CURVES"));
+    size_t batches_per_pass = cap / R.ub;
+    if (batches_per_pass < 1) batches_per_pass = 1;
+    const size_t npasses = (R.nbatches + batches_per_pass - 1) / batches_per_pass;
+    /* two sets of contexts when there is more than one pass to overlap (one prime range only: with several, a pass
+     * takes minutes to hours and its checkpoints are written as it goes) — and when two passes' worth of device memory
+     * is there: a full pass that needs more than 45 % of it stays alone on its GPU */
+    const size_t pass_curves_per_gpu = (batches_per_pass * R.ub + (size_t)gpus - 1) / (size_t)gpus;
+    const int room = !mem_free || 2 * gecm_batch_bytes(ctx[0][0], pass_curves_per_gpu, R.do_stage2, R.B1, 0, 0) <= budget;
+    const int slots = (npasses > 1 && R.nranges == 1 && room && !getenv("GECM_NO_PIPELINE")) ? 2 : 1;
+    for (int s = 1; s < slots; s++)
         for (int g = 0; g < gpus; g++) {
             if (gecm_create(&ctx[s][g], g % devices, modulus, 52)) { fprintf(stderr, "%s\n", gecm_last_error()); return 2; }
             if (inf.ref_special_reduction && gecm_set_report_modulus(ctx[s][g], ndec)) { fprintf(stderr, "%s\n", gecm_last_error()); return 2; }

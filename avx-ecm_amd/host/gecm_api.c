@@ -20,6 +20,9 @@
 #include <unistd.h>
 
 #define LIMB_BITS 28
+/* stage 2: giant steps per device chunk (one inversion each) and ring size (power of two >= chunk + 2L) */
+#define S2_GIANT_CHUNK 512u
+#define S2_RING 1024u
 /* largest B1: the 32-bit offsets of a range's tape and uint32 range indices are nowhere near it; the cap is the
  * reference's own (its prime sieve serves ranges below 10^13 or so; ecm.c keeps primes in 64 bits) kept at a size one
  * can still test */
@@ -405,6 +408,35 @@ int gecm_get_config(const gecm_ctx *c, gecm_config *cfg)
     cfg->device = c->device;
     cfg->rho = c->rho_ref;
     return GECM_OK;
+}
+
+int gecm_device_memory(gecm_ctx *c, uint64_t *free_bytes, uint64_t *total_bytes)
+{
+    if (!c) return GECM_ERR_ARG;
+    if (gecm_dev_memory(c->dev, free_bytes, total_bytes)) { set_err("%s", gecm_dev_error()); return GECM_ERR_DEVICE; }
+    return GECM_OK;
+}
+
+/* Device bytes a batch of `curves` curves takes: the stage-1 arrays and, with_stage2, the stage-2 allocations for wheel D
+ * and height U (0 = the defaults for B1) — the baby-step table is the largest allocation of the path.
+ * The same sums the device layer allocates by. */
+uint64_t gecm_batch_bytes(const gecm_ctx *c, size_t curves, int with_stage2, uint64_t B1, uint32_t D, uint32_t U)
+{
+    if (!c || !curves) return 0;
+    uint32_t npb = 0;
+    if (with_stage2) {
+        if (!D) D = gecm_s2_default_D(B1 ? B1 : 1000000);
+        if (!U) U = GECM_S2_DEFAULT_U;
+        gecm_s2_plan p;
+        memset(&p, 0, sizeof p);
+        if (gecm_s2_plan_init(&p, D, U) == 0) {
+            npb = p.npb;
+            gecm_s2_plan_free(&p);
+        }
+    }
+    uint64_t b = gecm_dev_batch_bytes(c->dev, curves, npb, S2_GIANT_CHUNK, S2_RING);
+    if (c->dev_f) b += gecm_dev_batch_bytes(c->dev_f, curves, 0, 0, 0);
+    return b;
 }
 
 int gecm_device_name(gecm_ctx *c, char *buf, size_t len)
@@ -1070,9 +1102,6 @@ int gecm_stage1_factor(gecm_ctx *c, size_t k, char *dec, size_t declen, int *is_
 }
 
 /* ---- stage 2 -------------------------------------------------------------------------------- */
-/* giant steps per device chunk (one inversion each) and ring size (power of two >= chunk + 2L) */
-#define S2_GIANT_CHUNK 512u
-#define S2_RING 1024u
 /* point additions next_pt_vec performs for multiplier c (one per bit below the top one, ecm.c:939-966) */
 static uint64_t ladder_adds(uint64_t c)
 {

@@ -100,7 +100,9 @@ class RangeDesc(ctypes.Structure):
 
 
 _sig("gecm_set_report_modulus", c_int, c_void_p, c_char_p)
-EXPORTS += ["gecm_set_report_modulus"]
+_sig("gecm_device_memory", c_int, c_void_p, ctypes.POINTER(c_u64), ctypes.POINTER(c_u64))
+_sig("gecm_batch_bytes", c_u64, c_void_p, c_size_t, c_int, c_u64, ctypes.c_uint32, ctypes.c_uint32)
+EXPORTS += ["gecm_set_report_modulus", "gecm_device_memory", "gecm_batch_bytes"]
 _sig("gecm_last_kernel_name", c_int, c_void_p, c_char_p, c_size_t)
 _sig("gecm_stage1_progress", c_int, c_void_p, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32))
 EXPORTS += ["gecm_last_kernel_name", "gecm_stage1_progress"]
@@ -270,6 +272,14 @@ class Engine:
     def lanes_per_curve(self):
         """what the last stage-1 launch used"""
         return _chk(lib.gecm_get_lanes_per_curve(self._h), "gecm_get_lanes_per_curve")
+
+    def device_memory(self):
+        f, t = c_u64(0), c_u64(0)
+        _chk(lib.gecm_device_memory(self._h, ctypes.byref(f), ctypes.byref(t)), "gecm_device_memory")
+        return f.value, t.value
+
+    def batch_bytes(self, curves, with_stage2=False, b1=0, D=0, U=0):
+        return lib.gecm_batch_bytes(self._h, curves, 1 if with_stage2 else 0, b1, D, U)
 
     def set_report_modulus(self, n):
         """save lines name n and factors are reported of n (a divisor of the context's modulus): the reference's

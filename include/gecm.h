@@ -63,6 +63,11 @@ typedef struct {
 } gecm_config;
 int gecm_get_config(const gecm_ctx *ctx, gecm_config *cfg);
 int gecm_device_name(gecm_ctx *ctx, char *buf, size_t len);
+/* free and total device memory right now (hipMemGetInfo), and the device bytes a batch of `curves` curves takes (stage 1
+ * only, or with the stage-2 tables of wheel D and height U; 0 = the defaults for B1): what a caller sizes its batches
+ * with.  The reference has no counterpart (its tables are per thread, ecm_work_init).                                */
+int gecm_device_memory(gecm_ctx *ctx, uint64_t *free_bytes, uint64_t *total_bytes);
+uint64_t gecm_batch_bytes(const gecm_ctx *ctx, size_t curves, int with_stage2, uint64_t B1, uint32_t D, uint32_t U);
 /* "one" = R mod N in the reference limb format, single value (monty->one, main.c:633-634) */
 int gecm_get_one(const gecm_ctx *ctx, void *one_limbs);
 

@@ -201,3 +201,45 @@ def test_cli_pipelined_passes_write_the_same_file():
     serial = _run([c["N"], 4096, 300, 1, 300, 7000], env={"GECM_PASS_CURVES": "512", "GECM_NO_PIPELINE": "1"})
     assert len(one[1].splitlines()) == 4096 and one[1] == piped[1] == serial[1]
     assert "Commencing curves 3584-4095 of 4096" in piped[0]
+
+
+def test_cli_without_sigma_draws_one_per_lane_and_thread():
+    """no sigma on the command line: every lane of every thread draws its own (ecm.c:1564-1570), so a batch is
+    8 x threads distinct curves; two runs differ"""
+    c = S1["K1N_two_full_batches_b1_500"]
+    outs = [_run([c["N"], 40, 200, 3, 200]) for _ in range(2)]
+    for out, save, res in outs:
+        lines = save.splitlines()
+        assert len(lines) == 48 and "using 3 threads (14 curves/thread)" in out      # 14 per thread -> two batches of 24 lines
+        sig = [int(l.split("SIGMA=")[1].split(";")[0]) for l in lines]
+        assert len(set(sig)) == 48 and min(sig) >= 6
+    assert outs[0][1] != outs[1][1]
+
+
+def test_batch_memory_figure_is_what_a_batch_takes():
+    """gecm_batch_bytes (what the driver sizes its passes with) against what a batch really takes on the device"""
+    import pyecm
+    n = int(S1["K1N_two_full_batches_b1_500"]["save_lines"][0].split("N=0x")[1].split(";")[0], 16)
+    for curves in (4096, 32768):
+        eng = pyecm.Engine(n)
+        free0, total = eng.device_memory()
+        assert total > 100 * 2 ** 30 and free0 <= total
+        eng.build_curves(list(range(1000, 1000 + curves)))
+        eng.stage1(300)
+        eng.scan_factors(1)
+        free1, _ = eng.device_memory()
+        eng.stage2(30000)
+        free2, _ = eng.device_memory()
+        s1, s2 = eng.batch_bytes(curves, False), eng.batch_bytes(curves, True, 300)
+        slack = 512 << 20                                            # the runtime's own pools, tape, constants, granularity
+        assert 0 < (free0 - free1) <= s1 + slack
+        assert s2 - slack <= (free0 - free2) <= s2 + slack, (curves, free0 - free2, s2)
+        if curves == 32768:
+            assert 0.9 * s2 <= (free0 - free2) <= 1.1 * s2, (free0 - free2, s2)
+        eng.close()
+    # BASELINE configs[3]'s slice and the largest class: what a full pass takes
+    eng = pyecm.Engine(n)
+    full = eng.batch_bytes(131072, True, 1000000)
+    assert 80e9 < full < 95e9        # 60 GB of table (7683 entries x 15 limbs x 4 B x 131072 curves) + ring, chunk and block scratch
+    assert eng.batch_bytes(131072, False) < 0.01 * full
+    eng.close()
