@@ -44,7 +44,14 @@
 #include <unistd.h>
 
 #define MAX_GPUS 16
-#define VECLEN 8
+/* The reference is built in two flavours (avx_ecm.h:65-93): DIGITBITS = 52 with VECLEN = 8 curves per vector, and
+ * DIGITBITS = 32 with VECLEN = 16.  The flavour decides the NWORDS/MAXBITS rule and its banner lines, the size of a batch
+ * (VECLEN x threads lines) and therefore where a run stops, never a residue.  This source builds both: avx-ecm and
+ * avx-ecm-32 (Makefile: -DGECM_CLI_DIGITBITS=32). */
+#ifndef GECM_CLI_DIGITBITS
+#define GECM_CLI_DIGITBITS 52
+#endif
+#define VECLEN (GECM_CLI_DIGITBITS == 52 ? 8 : 16)
 /* distinct curves per GPU per pass: 2 wavefronts on each of the 1024 SIMDs of an MI355X */
 #define FULL_BATCH 131072u
 #define PRIME_RANGE 100000000ULL
@@ -643,7 +650,7 @@ int main(int argc, char **argv)
     /* main.c:393-457: evaluate the expression, recognise Cunningham-type inputs, strip algebraic factors */
     static char ndec[MPL_MAXL * 10 + 16], prep_log[65536];
     gecm_input_info inf;
-    if (gecm_prepare_input(argv[1], 52, ndec, sizeof ndec, &inf, prep_log, sizeof prep_log)) {
+    if (gecm_prepare_input(argv[1], GECM_CLI_DIGITBITS, ndec, sizeof ndec, &inf, prep_log, sizeof prep_log)) {
         fputs(prep_log, stdout);
         printf("input must evaluate to an odd integer >= 3 (operators + - * / %% ^ ! # fib() luc())\n");
         return 1;
@@ -674,7 +681,7 @@ int main(int argc, char **argv)
     if (numcurves == 0 || R.B1 < 2 || R.B1 > 1000000000000ULL) { printf("need curves >= 1 and 2 <= B1 <= 1e12\n"); return 1; }
     R.nranges = gecm_stage1_ranges(R.B1);
     /* main.c:585-589: at least one curve per thread, the same number on every thread; ecm.c:1151: every thread
-     * runs whole vectors of VECLEN = 8, so "10 curves" on one thread writes 16 resume lines there and here */
+     * runs whole vectors of VECLEN curves, so "10 curves" on one thread writes 16 resume lines there and here */
     if (numcurves < (size_t)R.threads) numcurves = (size_t)R.threads;
     R.per_thread = numcurves / (size_t)R.threads + (numcurves % (size_t)R.threads != 0);
     R.nbatches = (R.per_thread + VECLEN - 1) / VECLEN;
@@ -685,7 +692,7 @@ int main(int argc, char **argv)
     if (!R.rd) { fprintf(stderr, "out of memory\n"); return 2; }
     R.rd_pending = pthread_create(&R.rd_thread, NULL, describe_ranges, &R) == 0;
     if (!R.rd_pending) describe_ranges(&R);
-    /* Special-form inputs for which the reference leaves REDC    /* Special-form inputs for which the reference leaves REDC (main.c:505-527, 642-684): it then works modulo
+    /* Special-form inputs for which the reference leaves REDC (main.c:505-527, 642-684): it then works modulo
      * Mw = 2^k - 1, 2^k + 1 or 2^k - c throughout, curve construction included, and keeps the number given for the "N="
      * of its files and for its factor checks (ecm.c:1111-1118).  Same here: the contexts are made on Mw and report
      * against N (gecm_set_report_modulus); the files come out as the reference's, byte for byte. */
@@ -702,7 +709,7 @@ int main(int argc, char **argv)
     }
     static gecm_ctx *ctx[2][MAX_GPUS];
     for (int g = 0; g < gpus; g++) {
-        if (gecm_create(&ctx[0][g], g % devices, modulus, 52)) { fprintf(stderr, "%s\n", gecm_last_error()); return 2; }
+        if (gecm_create(&ctx[0][g], g % devices, modulus, GECM_CLI_DIGITBITS)) { fprintf(stderr, "%s\n", gecm_last_error()); return 2; }
         if (inf.ref_special_reduction && gecm_set_report_modulus(ctx[0][g], ndec)) { fprintf(stderr, "%s\n", gecm_last_error()); return 2; }
     }
     /* passes: as many reference batches as fit FULL_BATCH distinct curves per GPU — or what the device's memory takes
@@ -727,7 +734,7 @@ int main(int argc, char **argv)
     const int slots = (npasses > 1 && R.nranges == 1 && room && !getenv("GECM_NO_PIPELINE")) ? 2 : 1;
     for (int s = 1; s < slots; s++)
         for (int g = 0; g < gpus; g++) {
-            if (gecm_create(&ctx[s][g], g % devices, modulus, 52)) { fprintf(stderr, "%s\n", gecm_last_error()); return 2; }
+            if (gecm_create(&ctx[s][g], g % devices, modulus, GECM_CLI_DIGITBITS)) { fprintf(stderr, "%s\n", gecm_last_error()); return 2; }
             if (inf.ref_special_reduction && gecm_set_report_modulus(ctx[s][g], ndec)) { fprintf(stderr, "%s\n", gecm_last_error()); return 2; }
         }
     gecm_config cfg;

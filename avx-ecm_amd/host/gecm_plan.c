@@ -174,6 +174,12 @@ int gecm_tape_append_prac(gecm_tape_t *t, uint64_t c)
 static uint64_t g_prime_range = GECM_PRIME_RANGE;
 /* test hook: walk the multi-range path with short ranges (tests compare with the oracle run the same way) */
 void gecm_plan_set_prime_range_for_tests(uint64_t range) { g_prime_range = range ? range : GECM_PRIME_RANGE; }
+/* the same hook for a whole process (the command-line driver under test): GECM_TEST_PRIME_RANGE=n, read once */
+__attribute__((constructor)) static void prime_range_from_env(void)
+{
+    const char *e = getenv("GECM_TEST_PRIME_RANGE");
+    if (e && atoll(e) >= 16) g_prime_range = (uint64_t)atoll(e);
+}
 
 typedef struct {
     const uint64_t *primes;

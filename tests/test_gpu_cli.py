@@ -129,14 +129,15 @@ def test_cli_fourth_argument_is_the_reference_s_thread_count():
     assert lines == c["save_lines"][:8] * 16                          # every thread: the reference's eight sigmas
 
 
-def _run_many(cmds):
+def _run_many(cmds, exes=None):
     """several driver processes at once (each a handful of curves: the GPU has room), one directory each"""
     import shutil
     dirs, procs = [], []
-    for args in cmds:
+    for i, args in enumerate(cmds):
         d = tempfile.mkdtemp()
         dirs.append(d)
-        procs.append(subprocess.Popen([EXE] + [str(a) for a in args], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+        procs.append(subprocess.Popen([exes[i] if exes else EXE] + [str(a) for a in args], cwd=d, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
     outs = []
     for d, p in zip(dirs, procs):
         out, _ = p.communicate(timeout=1100)
@@ -153,7 +154,15 @@ def test_cli_multirange_b1_above_1e8():
     doublings repeated and 100000007 skipped in the second, then save_b1.txt — and, in the second case, stage 2 from
     B1 to 1.3e8.  Byte for byte the files of the reference (three minutes of its time per case; about as long here:
     eight curves are one wavefront's worth of latency)."""
-    outs = _run_many([[c["N"], c["curves"], c["B1"], 1, c["B2"], c["sigma0"]] for c in MULTI])
+    cmds = [[c["N"], c["curves"], c["B1"], 1, c["B2"], c["sigma0"]] for c in MULTI]
+    # and, at the same time, the REFERENCE's own program with its four work functions on the GPU (oracle/_ref/avx-ecm-52-l1,
+    # tests/test_gpu_dropin.py): its vececm drives the two ranges and writes checkpoint.txt itself
+    l1 = os.path.join(ROOT, "oracle", "_ref", "avx-ecm-52-l1")
+    outs = _run_many(cmds + ([cmds[0]] if os.path.exists(l1) else []), exes=[EXE] * len(cmds) + [l1])
+    if os.path.exists(l1):
+        out, save, ckpt, res = outs[-1]
+        assert ckpt == MULTI[0]["checkpoint_lines"] and save == MULTI[0]["save_lines"] and res == MULTI[0]["results_lines"]
+        assert "Saving checkpoint after p=99999989" in out
     for c, (out, save, ckpt, res) in zip(MULTI, outs):
         assert ckpt == c["checkpoint_lines"], c["name"]
         assert save == c["save_lines"], c["name"]
@@ -243,3 +252,26 @@ def test_batch_memory_figure_is_what_a_batch_takes():
     assert 80e9 < full < 95e9        # 60 GB of table (7683 entries x 15 limbs x 4 B x 131072 curves) + ring, chunk and block scratch
     assert eng.batch_bytes(131072, False) < 0.01 * full
     eng.close()
+
+
+EXE32 = os.path.join(ROOT, "avx-ecm_amd", "avx-ecm-32")
+
+
+@pytest.mark.parametrize("name", ["n1023_d32_b1_1000", "n1023_d32_b1_10000", "n415_d32_b1_10000", "K1N_d32_b1_2000"])
+def test_cli_32_bit_flavour_writes_what_the_reference_s_32_bit_build_writes(name):
+    """avx-ecm-32 = the reference built with DIGITBITS = 32 (avx_ecm.h:80-89): vectors of 16 curves — a batch is
+    16 x threads lines, so a run that finds a factor stops after 16 — and the 128-bit NWORDS rule in the banner;
+    fixtures from oracle/_ref/avx-ecm-32"""
+    c = S1[name]
+    with tempfile.TemporaryDirectory() as d:
+        p = subprocess.run([EXE32, c["N"], str(c["curves"]), str(c["B1"]), "1", str(c["B2"]), str(c["sigma0"])], cwd=d,
+                           capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stdout + p.stderr
+        save = open(os.path.join(d, "save_b1.txt")).read()
+        res = [l for l in open(os.path.join(d, "ecm_results.txt")).read().splitlines() if l.strip()] \
+            if os.path.exists(os.path.join(d, "ecm_results.txt")) else []
+    assert hashlib.sha256(save.encode()).hexdigest() == c["save_sha256"] and len(save.splitlines()) == 16
+    assert res == c["results_lines"]
+    assert "ECM has been configured with DIGITBITS = 32, VECLEN = 16, GMP_LIMB_BITS = 64" in p.stdout
+    assert "Choosing MAXBITS = %d, NWORDS = %d, NBLOCKS = %d" % (c["maxbits"], c["nwords"], c["nwords"] // 4) in p.stdout
+    assert "with %d point-adds and %d point-doubles" % (c["ptadds"], c["ptdups"]) in p.stdout

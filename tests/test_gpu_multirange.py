@@ -112,3 +112,63 @@ def test_cut_tape_is_the_same_stage1(short_ranges):
             out[(chunk, lanes)] = eng.save_lines()
             eng.close()
     assert len({tuple(v) for v in out.values()}) == 1
+
+
+# ---- the command-line driver over several prime ranges AND several reference batches ----
+# (the reference-made fixtures of tests/test_gpu_cli.py::test_cli_multirange_b1_above_1e8 are single batches: three
+# minutes of reference time each.  Here PRIME_RANGE is shortened for the driver process — GECM_TEST_PRIME_RANGE — and the
+# expected lines come from the oracle walked the same way; the ORDER expected is the reference's: it finishes a batch,
+# all its ranges and checkpoints, before it starts the next, ecm.c:1151-1312.)
+import subprocess
+import tempfile
+
+EXE = os.path.join(ROOT, "avx-ecm_amd", "avx-ecm")
+S1 = {c["name"]: c for c in json.load(open(os.path.join(GOLDEN, "stage1.json")))}
+
+
+def _cli(args, env):
+    with tempfile.TemporaryDirectory() as d:
+        p = subprocess.run([EXE] + [str(a) for a in args], cwd=d, capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+        assert p.returncode == 0, p.stdout + p.stderr
+        rd = lambda f: open(os.path.join(d, f)).read().splitlines() if os.path.exists(os.path.join(d, f)) else []
+        return p.stdout, rd("save_b1.txt"), rd("checkpoint.txt"), [l for l in rd("ecm_results.txt") if l.strip()]
+
+
+@pytest.mark.parametrize("threads,passes", [(1, {}), (2, {}), (1, {"GECM_PASS_CURVES": "8"}), (1, {"GECM_PASS_CURVES": "16"})])
+def test_cli_checkpoints_of_several_batches_come_in_the_reference_s_order(threads, passes):
+    c = S1["K1N_two_full_batches_b1_500"]                      # no small factors: nothing stops the run
+    n = int(c["save_lines"][0].split("N=0x")[1].split(";")[0], 16)
+    b1, prange, sigma0, batches = 2500, 1000, 300, 3
+    out, save, ckpt, res = _cli([c["N"], 8 * batches * threads, b1, threads, b1, sigma0], dict(passes, GECM_TEST_PRIME_RANGE=str(prange)))
+    L = _oracle()
+    o = L.orc_create(str(n).encode(), 52)
+    want_ckpt, want_save = [], []
+    for b in range(batches):
+        sig = [sigma0 + 8 * b + i for i in range(8)]
+        for r in (0, 1):                                        # ranges [0,1000) and [1000,2000) end below B1: checkpoints
+            lines = [_oracle_line(L, o, s, b1, b1, prange, r + 1, 0)[0].rstrip("\n") for s in sig]
+            want_ckpt += lines * threads                        # every thread of a batch: the same eight sigmas
+        want_save += [_oracle_line(L, o, s, b1, b1, prange, 0, b1)[0].rstrip("\n") for s in sig] * threads
+    L.orc_destroy(o)
+    assert ckpt == want_ckpt
+    assert save == want_save and res == []
+    assert out.count("Saving checkpoint after p=997") >= 1 and "Saving checkpoint after p=1999" in out
+    assert "Found 168 primes in range [0 : 1000]" in out and "Commencing Stage 1 @ prime 1009" in out
+
+
+def test_cli_checkpoint_factor_stops_after_its_batch():
+    """a modulus with small factors: the first batch finds one at the first checkpoint already; the reference reports
+    it there (B1 = the range's last prime, ecm.c:1262-1291), goes on to the end of stage 1, and stops after the batch"""
+    c = S1["n415_b1_1000"]
+    b1, prange = 2500, 1000
+    out, save, ckpt, res = _cli([c["N"], 24, b1, 1, b1, c["sigma0"]], {"GECM_TEST_PRIME_RANGE": str(prange)})
+    assert len(save) == 8 and len(ckpt) == 16                  # batch 0 only: two checkpoints, one save
+    assert [l.split("B1=")[1].split(";")[0] for l in ckpt] == ["997"] * 8 + ["1999"] * 8
+    assert [int(l.split("SIGMA=")[1].split(";")[0]) for l in save] == list(range(c["sigma0"], c["sigma0"] + 8))
+    labels = [l.split("in stage 1 (B1 = ")[1].split(")")[0] for l in res]
+    assert labels == sorted(labels, key=lambda x: (0, 1, 2)[["997", "1999", "2500"].index(x)])
+    assert set(labels) == {"997", "1999", "2500"} and all("curve " in l and "thread 0, vec " in l for l in res)
+    # the factor lines of the last range are the ones a plain run at that B1 cannot give (other residues), but every
+    # factor reported divides N
+    n = int(save[0].split("N=0x")[1].split(";")[0], 16)
+    assert all(n % int(l.split(" factor ")[1].split(" ")[0]) == 0 for l in res)
