@@ -66,6 +66,47 @@ def test_config_4096_curves_b1_1e6(name, other):
     assert [lines[k] for k in check] == _oracle_lines(n, [sig[k] for k in check], b1)
 
 
+def test_config4_4096_curves_1023_bits_32_bit_boundary_b1_1e5():
+    """BASELINE configs[4]: the DIGITBITS = 32 boundary (NWORDS = 32, MAXBITS = 1024), 1023-bit N, B1 = 1e5, the whole
+    4096-curve batch: one sha256 over all save lines through the layout the library picks (32 lanes per curve, three
+    limbs per lane, the crossbar variant) and through eight lanes per curve; the first 16 lanes against the lines the
+    reference's 32-bit build wrote; lanes 0, 63, 64, 4095 against the oracle in the 32-bit format"""
+    import pyecm
+    case = S1["n1023_d32_b1_100000"]
+    n = int(case["save_lines"][0].split("N=0x")[1].split(";")[0], 16)
+    b1, curves = 100000, 4096
+    sig = list(range(1000, 1000 + curves))
+    eng = pyecm.Engine(n, digitbits=32)
+    assert (eng.cfg.nwords, eng.cfg.maxbits, eng.cfg.dev_limbs) == (32, 1024, 37)
+    sha, lines = {}, None
+    for lanes in (0, 8):
+        eng.set_lanes_per_curve(lanes)
+        eng.build_curves(sig)
+        eng.stage1(b1)
+        used = eng.lanes_per_curve()
+        got = eng.save_lines()
+        sha[used] = hashlib.sha256("".join(got).encode()).hexdigest()
+        if lanes == 0:
+            assert used == 32 and eng.last_kernel_name() == "k_stage1_row<3, 39, true>"
+            lines = got
+            assert (eng.stage1_stats().ptadds, eng.stage1_stats().ptdups) == (case["ptadds"], case["ptdups"]) == (195448, 23269)
+    eng.close()
+    assert len(sha) == 2 and len(set(sha.values())) == 1, sha
+    assert [l.rstrip("\n") for l in lines[:16]] == case["save_lines"]
+    L = ctypes.CDLL(os.path.join(ROOT, "oracle", "libecm_oracle.so"))
+    L.orc_create.restype = ctypes.c_void_p
+    L.orc_create.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    L.orc_destroy.argtypes = [ctypes.c_void_p]
+    L.orc_stage1_line.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_char_p, ctypes.c_size_t,
+                                  ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint64)]
+    c = L.orc_create(str(n).encode(), 32)
+    buf = ctypes.create_string_buffer(8192)
+    for k in (0, 63, 64, 4095):
+        L.orc_stage1_line(c, sig[k], b1, buf, len(buf), None, 0, None)
+        assert buf.value.decode() == lines[k], k
+    L.orc_destroy(c)
+
+
 def test_config3_slice_stage2_4096_curves_b2_1e8():
     import pyecm
     case = S1["T35_46"]
