@@ -731,7 +731,9 @@ int main(int argc, char **argv)
      * is there: a full pass that needs more than 45 % of it stays alone on its GPU */
     const size_t pass_curves_per_gpu = (batches_per_pass * R.ub + (size_t)gpus - 1) / (size_t)gpus;
     const int room = !mem_free || 2 * gecm_batch_bytes(ctx[0][0], pass_curves_per_gpu, R.do_stage2, R.B1, 0, 0) <= budget;
-    const int slots = (npasses > 1 && R.nranges == 1 && room && !getenv("GECM_NO_PIPELINE")) ? 2 : 1;
+    /* (B1 in (99999989, 1e8] is one range WITH a checkpoint, ecm.c:1237: checkpoint.txt is appended to inside a pass's
+     * turn on the GPU and put in order when the pass is written, which two passes in flight would do to each other) */
+    const int slots = (npasses > 1 && R.nranges == 1 && R.B1 <= 99999989ULL && room && !getenv("GECM_NO_PIPELINE")) ? 2 : 1;
     for (int s = 1; s < slots; s++)
         for (int g = 0; g < gpus; g++) {
             if (gecm_create(&ctx[s][g], g % devices, modulus, GECM_CLI_DIGITBITS)) { fprintf(stderr, "%s\n", gecm_last_error()); return 2; }
