@@ -172,3 +172,34 @@ def test_cli_checkpoint_factor_stops_after_its_batch():
     # factor reported divides N
     n = int(save[0].split("N=0x")[1].split(";")[0], 16)
     assert all(n % int(l.split(" factor ")[1].split(" ")[0]) == 0 for l in res)
+
+
+def test_ranges_with_the_special_form_multiply(short_ranges):
+    """N | 2^k - 1 at a batch size that takes the F-form context: every range runs there (its own copy of the range's
+    tape), the points come back modulo N between ranges, and the lines equal the generic path's and the oracle's"""
+    import pyecm
+    short_ranges(1500)
+    n = (1 << 401) - 1
+    b1 = 4000
+    sig = list(range(1000, 1000 + 200))
+    L = _oracle()
+    o = L.orc_create(str(n).encode(), 52)
+    out = {}
+    for special in (True, False):
+        eng = pyecm.Engine(n)
+        eng.set_special_form(special)
+        eng.set_lanes_per_curve(1)
+        eng.build_curves(sig)
+        per_range = []
+        for r in range(pyecm.stage1_ranges(b1)):
+            d = pyecm.describe_range(b1, b1, r)
+            eng.stage1_range(b1, r)
+            assert eng.special_form_used() == special
+            per_range.append([eng.resume_line(k, d.last_prime) for k in (0, 63, 64, 199)])
+        out[special] = per_range + [[eng.save_line(k) for k in (0, 63, 64, 199)]]
+        eng.close()
+    assert out[True] == out[False]
+    for r in range(3):
+        assert out[True][r][0] == _oracle_line(L, o, sig[0], b1, b1, 1500, r + 1, 0)[0]
+    assert out[True][3][3] == _oracle_line(L, o, sig[199], b1, b1, 1500, 0, b1)[0]
+    L.orc_destroy(o)
