@@ -1372,11 +1372,14 @@ static int fetch_acc(gecm_ctx *c)
     return GECM_OK;
 }
 
-/* The failed-inversion record of curve k: plane 0 (the single-chain inversions; after gecm_stage2_pair the
- * reference's last batch of the range) if it holds one; else the record of the last sub-sequence that holds a proper
- * divisor of N (the reference keeps the gcd of its last failing batch, ecm.c:1925-1939); the gcd of N with the
- * product of the records only when no single one is proper.  Every record is passed through gcd(., N) before it is
- * believed: what comes out divides N. */
+/* The failed-inversion record of curve k.  The reference overwrites its accumulator with gcd(product of the batch, N)
+ * every time a batch inversion fails (ecm.c:1925-1939): what its scan finds in the end is the gcd of the LAST failing
+ * batch (times later cross products).  Plane 0 holds that gcd for the single-chain inversions — after gecm_stage2_pair
+ * the last chunk of the range, cut to be exactly the reference's last batch — and decides when it holds one.  Otherwise
+ * the sub-sequences' planes stand for one batch inverted in K pieces: the gcd of N with the PRODUCT of their records
+ * is the gcd of the whole batch's product (for a product that covers N that is N itself — "no factor", which is
+ * what the reference finds then too: its batch product is 0 modulo N).  Every record is passed through gcd(., N)
+ * first: what comes out divides N. */
 static void fail_record(gecm_ctx *c, size_t k, mpl_t *g)
 {
     const size_t plane = c->batch * (size_t)c->nl;
@@ -1386,14 +1389,13 @@ static void fail_record(gecm_ctx *c, size_t k, mpl_t *g)
     mpl_set_u64(g, 0);
     if (c->fail_planes <= 1) return;
     mpl_set_u64(&prod, 0);
-    for (uint32_t p = c->fail_planes - 1; p >= 1; p--) {
+    for (uint32_t p = 1; p < c->fail_planes; p++) {
         mpl_from_limbs32(&t, c->hfail + p * plane + k, c->batch, c->nl, LIMB_BITS);
         if (mpl_is_zero(&t)) continue;
         mpl_gcd(&gp, &t, &c->N);
-        if (mpl_cmp_u64(&gp, 1) > 0 && mpl_cmp(&gp, &c->N) != 0) { *g = gp; return; }
-        if (mpl_is_zero(&prod)) prod = t;
-        else mpl_mulmod(&prod, &prod, &t, &c->N);
-        if (mpl_is_zero(&prod)) prod = c->N;                  /* the product covers N */
+        if (mpl_is_zero(&prod)) prod = gp;
+        else mpl_mulmod(&prod, &prod, &gp, &c->N);
+        if (mpl_is_zero(&prod)) { prod = c->N; break; }       /* the product covers N: gcd = N, "no factor" */
     }
     if (!mpl_is_zero(&prod)) mpl_gcd(g, &prod, &c->N);
 }

@@ -214,8 +214,11 @@ int gecm_tape_build_stage1_range(gecm_tape_t *t, uint64_t B1, uint32_t range, in
 {
     memset(t, 0, sizeof *t);
     if (range >= gecm_stage1_ranges_plan(B1)) return -2;
+    /* PRIMES = the primes of [rangemin, rangemax], both ends included (GetPRIMESRange; a prime AT a range boundary —
+     * impossible with the reference's 1e8, possible with the short ranges tests use — ends one list and heads the next,
+     * where it is skipped), of which the call uses those below B1 */
     const uint64_t lo = (uint64_t)range * g_prime_range;
-    const uint64_t hi = lo + g_prime_range < B1 ? lo + g_prime_range : B1;
+    const uint64_t hi = lo + g_prime_range + 1 < B1 ? lo + g_prime_range + 1 : B1;
     uint64_t q = 2;
     while (q < B1) {                                    /* ecm.c:1815-1822 */
         if (tape_push(t, GECM_OP_PRAC_BEGIN)) return -1;

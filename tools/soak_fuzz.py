@@ -92,33 +92,42 @@ while time.time() < t_end:
                       (name, n, b1, prange, chunk, digitbits, batch, special, lanes, [sig[k] for k in pick]), flush=True)
                 sys.exit(1)
             flavours += 1
-    # stage 2 now and then (one range of primes, the library's D and U): the factor each curve reports — from gcd(acc, N) or
-    # from the gcd a failing inversion left, as the reference keeps it — against the oracle's; accumulators too where the
-    # curve met no failing inversion
+    # stage 2 now and then (one range of primes, the library's D and U) on a modulus WITHOUT small factors — a product of
+    # Mersenne primes — so that no inversion fails and the accumulator is defined by the arithmetic alone: accumulator,
+    # factor and counters against the oracle's.  (Where inversions fail the reference reports the gcd of its last failing
+    # batch times whatever its later products — made with the operand mpz_invert left behind — happen to contain; the
+    # oracle restates that, the HIP path reports the gcd alone, DESIGN.md §7: such lanes are pinned by the fixtures.)
     s2 = ""
-    if not prange and rng.random() < 0.4 and b1 < 6000:
-        b2 = b1 + rng.randrange(500, 60000)
-        eng.set_special_form(False)
-        eng.set_lanes_per_curve(0)
+    if rng.random() < 0.3:
+        eng.close()
+        M = {e: (1 << e) - 1 for e in (61, 89, 107, 127, 521, 607)}
+        n2 = rng.choice([M[127] * M[89], M[127] * M[107] * M[89] * M[61], M[521], M[521] * M[127], M[607] * M[127] * M[89],
+                         M[607] * M[127] * M[107] * M[89] * M[61], M[521] * M[107] * M[89], M[607] * M[521] // 1])
+        d2 = rng.choice((52, 32)) if n2.bit_length() < 1000 else 32
+        b1s = rng.randrange(30, 5000)
+        b2 = b1s + rng.randrange(500, 200000)
+        hook(0)
+        os.environ.pop("GECM_TAPE_CHUNK", None)
+        eng = pyecm.Engine(n2, digitbits=d2)
         eng.build_curves(sig)
-        eng.stage1(b1)
+        eng.stage1(b1s)
         eng.stage2(b2)
         st = eng.stage2_stats()
         acc = eng.download_acc()
-        o = L.orc_create(str(n).encode(), digitbits)
+        o = L.orc_create(str(n2).encode(), d2)
         acch = ctypes.create_string_buffer(16384)
         fac = ctypes.create_string_buffer(4096)
         cnt = (ctypes.c_uint64 * 3)()
         for k in pick:
-            L.orc_stage2(o, sig[k], b1, b2, st.D, st.U, acch, fac, len(fac), cnt)
+            L.orc_stage2(o, sig[k], b1s, b2, st.D, st.U, acch, fac, len(fac), cnt)
             f = eng.stage2_factor(k)
             wf = int(fac.value) if fac.value else None
-            if (f[0] if f else None) != wf or (wf is None and int(acch.value, 16) != acc[k]) or list(cnt) != [st.ptadds, st.numinv, st.paired]:
-                print("STAGE-2 DIFFERENCE: %s n=%d b1=%d b2=%d D=%d U=%d digitbits=%d batch=%d sigma=%d: factor %s vs oracle %s, counters %s vs %s" %
-                      (name, n, b1, b2, st.D, st.U, digitbits, batch, sig[k], f, wf, [st.ptadds, st.numinv, st.paired], list(cnt)), flush=True)
+            if (f[0] if f else None) != wf or int(acch.value, 16) != acc[k] or list(cnt) != [st.ptadds, st.numinv, st.paired]:
+                print("STAGE-2 DIFFERENCE: n=%d b1=%d b2=%d D=%d U=%d digitbits=%d batch=%d sigma=%d: factor %s vs oracle %s, counters %s vs %s" %
+                      (n2, b1s, b2, st.D, st.U, d2, batch, sig[k], f, wf, [st.ptadds, st.numinv, st.paired], list(cnt)), flush=True)
                 sys.exit(1)
         L.orc_destroy(o)
-        s2 = " stage2(B2=%d, D=%d)" % (b2, st.D)
+        s2 = " stage2(%d bits, B1=%d, B2=%d, D=%d)" % (n2.bit_length(), b1s, b2, st.D)
     eng.close()
     done += 1
     print("%4d ok %-22s %4d bits b1=%-6d ranges=%-5s chunk=%-5d d%d batch=%-3d %s" % (done, name, n.bit_length(), b1, prange or "-", chunk, digitbits, batch, " ".join(tried) + s2), flush=True)
