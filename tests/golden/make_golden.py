@@ -28,7 +28,7 @@ into oracle/_ref/).  The fixtures are data (inputs + outputs); no reference sour
 
   special.json : special-form inputs end to end (stage 1 and stage 2): the reference works modulo 2^k -/+ 1 or 2^k - c
 
-usage: python tests/golden/make_golden.py [--only stage1|l0|inputs|stage2acc|multirange|batches|special] [--quick]
+usage: python tests/golden/make_golden.py [--only stage1|l0|inputs|stage2acc|multirange|batches|special|degenerate] [--quick]
 """
 import json, os, random, re, subprocess, sys, tempfile, hashlib
 
@@ -358,6 +358,18 @@ def gen_special():
     json.dump(cases, open(os.path.join(HERE, "special.json"), "w"), indent=1)
 
 
+def gen_degenerate():
+    """A modulus made of many small primes (the cofactor of 2^496 - 1 times a 98-bit prime, so that the reference stays
+    with REDC): stage-2 inversions fail batch after batch, with different gcds, and the reference's accumulator ends as
+    the gcd of its last failing batch times whatever its later products contain (ecm.c:1925-1939).  Found by
+    tools/soak_fuzz.py; pins the oracle's restatement of that behaviour."""
+    n = 3121796185145477483418392554386586511231252428132929722174497757015462917147969171896000316935515523337612234042458296148257855102126147338567681
+    p = 297467847534123075601765177943
+    c = run_ref(52, n * p, 8, 65, 50085, 768295079280089151, keep_stdout=True)
+    c["name"] = "many_small_primes_b1_65_b2_50085"
+    json.dump([c], open(os.path.join(HERE, "degenerate.json"), "w"), indent=1)
+
+
 def gen_batches():
     """More curves than one reference batch (8 x threads)."""
     n415 = rand_n(415)
@@ -398,3 +410,5 @@ if __name__ == "__main__":
         gen_batches()
     if only in (None, "special"):
         gen_special()
+    if only in (None, "degenerate"):
+        gen_degenerate()

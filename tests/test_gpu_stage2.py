@@ -298,3 +298,39 @@ def test_sliced_pair_walk_equals_single_accumulator(batch):
     for k in (0, 63, 64, batch // 2, batch - 1):
         L.orc_stage2(c, sig[k], b1, b2, D, U, acch, None, 0, None)
         assert int(acch.value, 16) == accs[0][k]
+
+
+def test_stage2_on_a_modulus_of_many_small_primes_reports_the_last_failing_batch():
+    """tests/golden/degenerate.json (a reference run found through tools/soak_fuzz.py): every stage-2 batch inversion of
+    these curves fails, with different gcds.  The reference ends with the gcd of its LAST failing batch times whatever
+    its later products — made with the operand mpz_invert left behind — happen to contain; the HIP path does not restate
+    that left-over operand and reports the gcd alone.  So: save lines and stage-1 factors are the
+    reference's byte for byte, counters equal, and every stage-2 factor is a proper factor of N that DIVIDES the
+    reference's — in every configuration of sub-sequences and slices."""
+    import pyecm
+    case = json.load(open(os.path.join(GOLDEN, "degenerate.json")))[0]
+    n = int(case["save_lines"][0].split("N=0x")[1].split(";")[0], 16)
+    want1 = {int(re.search(r"vec (\d+),", l).group(1)): int(re.search(r"factor (\d+) in", l).group(1)) for l in case["results_lines"] if "in stage 1" in l}
+    want2 = {int(re.search(r"vec (\d+),", l).group(1)): int(re.search(r"factor (\d+) in", l).group(1)) for l in case["results_lines"] if "in stage 2" in l}
+    for env in ({}, {"GECM_S2_SUBSEQ": "1"}, {"GECM_S2_SUBSEQ": "4", "GECM_S2_SLICES": "1"}):
+        for k in ("GECM_S2_SUBSEQ", "GECM_S2_SLICES"):
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        try:
+            eng = pyecm.Engine(n)
+            eng.build_curves([case["sigma0"] + k for k in range(8)])
+            eng.stage1(case["B1"])
+            assert [l.rstrip("\n") for l in eng.save_lines()] == case["save_lines"]
+            assert {k: eng.stage1_factor(k)[0] for k in range(8)} == want1
+            eng.stage2(case["B2"])
+            st = eng.stage2_stats()
+            assert [st.ptadds, st.numinv, st.paired] == case["stage2_counts"]
+            eng.scan_factors(2)
+            for k in range(8):
+                f = eng.stage2_factor(k)
+                assert f and eng.curve_flag(2, k)
+                assert 1 < f[0] < n and n % f[0] == 0 and want2[k] % f[0] == 0, (env, k, f[0], want2[k])
+            eng.close()
+        finally:
+            for k in env:
+                os.environ.pop(k, None)

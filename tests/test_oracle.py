@@ -240,3 +240,27 @@ def test_oracle_modulo_the_special_modulus_gives_the_reference_s_residues(orc, c
         for key in ("X", "Z"):
             assert got.split(key + "=0x")[1].split(";")[0] == want.split(key + "=0x")[1].split(";")[0], (case["name"], k, key)
     orc.orc_destroy(c)
+
+
+# ---- a modulus of many small primes: stage-2 inversions fail batch after batch (found by tools/soak_fuzz.py) ----
+DEGENERATE = json.load(open(os.path.join(GOLDEN, "degenerate.json"))) if os.path.exists(os.path.join(GOLDEN, "degenerate.json")) else []
+
+
+@pytest.mark.parametrize("case", DEGENERATE, ids=[c["name"] for c in DEGENERATE])
+def test_oracle_restates_what_the_reference_does_after_a_failing_inversion(orc, case):
+    """every batch inversion of these curves fails, with different gcds; the reference overwrites its accumulator with the
+    gcd each time and multiplies on with the operand mpz_invert left behind (ecm.c:1925-1950): the oracle follows it to the
+    factor lines of all eight lanes, stage 1 and stage 2"""
+    n = int(case["save_lines"][0].split("N=0x")[1].split(";")[0], 16)
+    c = orc.orc_create(str(n).encode(), 52)
+    line = ctypes.create_string_buffer(16384)
+    fac = ctypes.create_string_buffer(4096)
+    want1 = {int(re.search(r"vec (\d+),", l).group(1)): int(re.search(r"factor (\d+) in", l).group(1)) for l in case["results_lines"] if "in stage 1" in l}
+    want2 = {int(re.search(r"vec (\d+),", l).group(1)): int(re.search(r"factor (\d+) in", l).group(1)) for l in case["results_lines"] if "in stage 2" in l}
+    assert len(want1) == len(want2) == 8
+    for k in range(8):
+        orc.orc_stage1_line(c, case["sigma0"] + k, case["B1"], line, len(line), fac, len(fac), None)
+        assert line.value.decode().rstrip("\n") == case["save_lines"][k] and int(fac.value) == want1[k]
+        acc, f2, cnt = _orc_stage2(orc, c, case["sigma0"] + k, case["B1"], case["B2"], 60)
+        assert f2 == want2[k] and cnt == case["stage2_counts"]
+    orc.orc_destroy(c)

@@ -102,7 +102,7 @@ while time.time() < t_end:
         eng.close()
         M = {e: (1 << e) - 1 for e in (61, 89, 107, 127, 521, 607)}
         n2 = rng.choice([M[127] * M[89], M[127] * M[107] * M[89] * M[61], M[521], M[521] * M[127], M[607] * M[127] * M[89],
-                         M[607] * M[127] * M[107] * M[89] * M[61], M[521] * M[107] * M[89], M[607] * M[521] // 1])
+                         M[607] * M[127] * M[107] * M[89] * M[61], M[521] * M[107] * M[89]])
         d2 = rng.choice((52, 32)) if n2.bit_length() < 1000 else 32
         b1s = rng.randrange(30, 5000)
         b2 = b1s + rng.randrange(500, 200000)
