@@ -360,9 +360,9 @@ def gen_special():
 
 def gen_degenerate():
     """A modulus made of many small primes (the cofactor of 2^496 - 1 times a 98-bit prime, so that the reference stays
-    with REDC): stage-2 inversions fail batch after batch, with different gcds, and the reference's accumulator ends as
-    the gcd of its last failing batch times whatever its later products contain (ecm.c:1925-1939).  Found by
-    tools/soak_fuzz.py; pins the oracle's restatement of that behaviour."""
+    with REDC): stage-2 inversions fail batch after batch, with different gcds, differential additions degenerate modulo
+    the small primes, and the reference's accumulator ends as the gcd of its last failing batch (ecm.c:1925-1939).  Found
+    by tools/soak_fuzz.py; pins the oracle's restatement of that behaviour and the HIP path's contract there."""
     n = 3121796185145477483418392554386586511231252428132929722174497757015462917147969171896000316935515523337612234042458296148257855102126147338567681
     p = 297467847534123075601765177943
     c = run_ref(52, n * p, 8, 65, 50085, 768295079280089151, keep_stdout=True)

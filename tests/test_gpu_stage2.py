@@ -301,12 +301,12 @@ def test_sliced_pair_walk_equals_single_accumulator(batch):
 
 
 def test_stage2_on_a_modulus_of_many_small_primes_reports_the_last_failing_batch():
-    """tests/golden/degenerate.json (a reference run found through tools/soak_fuzz.py): every stage-2 batch inversion of
-    these curves fails, with different gcds.  The reference ends with the gcd of its LAST failing batch times whatever
-    its later products — made with the operand mpz_invert left behind — happen to contain; the HIP path does not restate
-    that left-over operand and reports the gcd alone.  So: save lines and stage-1 factors are the
-    reference's byte for byte, counters equal, and every stage-2 factor is a proper factor of N that DIVIDES the
-    reference's — in every configuration of sub-sequences and slices."""
+    """tests/golden/degenerate.json (a reference run found through tools/soak_fuzz.py): a modulus of many small primes.
+    Every stage-2 batch inversion of these curves fails, with different gcds, and the curves' tiny orders modulo those
+    primes make differential additions degenerate — where, depends on the addition chain.  The plain chain (one
+    sub-sequence: the reference's own chain) reports the reference's factors on all eight lanes; the sub-sequence chains
+    of a small batch report proper factors of N that DIVIDE them.  Save lines, stage-1 factors and counters
+    are the reference's in every configuration."""
     import pyecm
     case = json.load(open(os.path.join(GOLDEN, "degenerate.json")))[0]
     n = int(case["save_lines"][0].split("N=0x")[1].split(";")[0], 16)
@@ -330,6 +330,8 @@ def test_stage2_on_a_modulus_of_many_small_primes_reports_the_last_failing_batch
                 f = eng.stage2_factor(k)
                 assert f and eng.curve_flag(2, k)
                 assert 1 < f[0] < n and n % f[0] == 0 and want2[k] % f[0] == 0, (env, k, f[0], want2[k])
+                if env.get("GECM_S2_SUBSEQ") == "1":
+                    assert f[0] == want2[k], (k, f[0], want2[k])       # the reference's own chain: the reference's factor
             eng.close()
         finally:
             for k in env:

@@ -248,9 +248,9 @@ DEGENERATE = json.load(open(os.path.join(GOLDEN, "degenerate.json"))) if os.path
 
 @pytest.mark.parametrize("case", DEGENERATE, ids=[c["name"] for c in DEGENERATE])
 def test_oracle_restates_what_the_reference_does_after_a_failing_inversion(orc, case):
-    """every batch inversion of these curves fails, with different gcds; the reference overwrites its accumulator with the
-    gcd each time and multiplies on with the operand mpz_invert left behind (ecm.c:1925-1950): the oracle follows it to the
-    factor lines of all eight lanes, stage 1 and stage 2"""
+    """every batch inversion of these curves fails, with different gcds, and differential additions degenerate modulo the
+    small primes; the reference overwrites its accumulator with the gcd of each failing batch (ecm.c:1925-1950), the last
+    one stays: the oracle — same chains, same batches — arrives at the factor lines of all eight lanes, stage 1 and 2"""
     n = int(case["save_lines"][0].split("N=0x")[1].split(";")[0], 16)
     c = orc.orc_create(str(n).encode(), 52)
     line = ctypes.create_string_buffer(16384)

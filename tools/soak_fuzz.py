@@ -94,9 +94,9 @@ while time.time() < t_end:
             flavours += 1
     # stage 2 now and then (one range of primes, the library's D and U) on a modulus WITHOUT small factors — a product of
     # Mersenne primes — so that no inversion fails and the accumulator is defined by the arithmetic alone: accumulator,
-    # factor and counters against the oracle's.  (Where inversions fail the reference reports the gcd of its last failing
-    # batch times whatever its later products — made with the operand mpz_invert left behind — happen to contain; the
-    # oracle restates that, the HIP path reports the gcd alone, DESIGN.md §7: such lanes are pinned by the fixtures.)
+    # factor and counters against the oracle's.  (Where inversions fail, the reported factor is the gcd of the last failing
+    # batch, and on moduli of many tiny primes that gcd depends on the addition chain — DESIGN.md §7; such lanes are pinned
+    # by fixtures, tests/golden/degenerate.json among them.)
     s2 = ""
     if rng.random() < 0.3:
         eng.close()
