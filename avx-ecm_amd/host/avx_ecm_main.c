@@ -100,7 +100,8 @@ typedef struct {
     pthread_mutex_t mu;
     pthread_cond_t cv;
     size_t gpu_turn, out_turn;
-    int found, failed;
+    size_t found_pass;         /* the pass that found a factor (SIZE_MAX: none yet): later passes are not run, not written */
+    int failed;
     uint64_t lcg;
     double t_start;
 } run_t;
@@ -447,7 +448,7 @@ static void *pass_run(void *arg)
     /* the GPUs, in pass order */
     pthread_mutex_lock(&R->mu);
     while (R->gpu_turn != ps->index && !R->failed) pthread_cond_wait(&R->cv, &R->mu);
-    const int stop = R->found || R->failed;
+    const int stop = R->found_pass < ps->index || R->failed;
     pthread_mutex_unlock(&R->mu);
     if (stop) {                                   /* an earlier pass found a factor: this one is not run at all */
         pthread_mutex_lock(&R->mu);
@@ -558,20 +559,22 @@ static void *pass_run(void *arg)
         text_printf(&s2log, "performed %lu pt-adds, %lu inversions, and %lu pair-muls in stage 2\n",
                     (unsigned long)s2.ptadds, (unsigned long)s2.numinv, (unsigned long)s2.paired); /* ecm.c:1482 */
     }
-    /* the GPUs go to the next pass */
-    pthread_mutex_lock(&R->mu);
-    R->gpu_turn = ps->index + 1;
-    pthread_cond_broadcast(&R->cv);
-    pthread_mutex_unlock(&R->mu);
-
-    /* host: what the reference would have written for these batches, one after the other.  The first batch in which
-     * anything was found — at a checkpoint, after stage 1 or after stage 2 — is the last one written. */
+    /* What the reference would have written for these batches, one after the other: the first batch in which anything
+     * was found — at a checkpoint, after stage 1 or after stage 2 — is the last one written.  Known from the device
+     * scans alone, so it is settled before the GPUs go on: a pass behind a factor is not even started. */
     size_t bstar = ps->nb;
     for (int c = 0; c < ps->nck; c++)
         if (ps->ck[c].first_flagged < bstar) bstar = ps->ck[c].first_flagged;
     for (size_t b = 0; b < bstar; b++)
         if (batch_flagged(ps, 1, b) || (R->do_stage2 && batch_flagged(ps, 2, b))) { bstar = b; break; }
     const int found = bstar < ps->nb;
+    /* the GPUs go to the next pass */
+    pthread_mutex_lock(&R->mu);
+    if (found && R->found_pass > ps->index) R->found_pass = ps->index;
+    R->gpu_turn = ps->index + 1;
+    pthread_cond_broadcast(&R->cv);
+    pthread_mutex_unlock(&R->mu);
+
     const size_t nwrite = found ? bstar + 1 : ps->nb;
     char **lines = format_lines(ps, R->B1, nwrite * R->ub);
     text_t res = {0, 0, 0}, out1 = {0, 0, 0}, out2 = {0, 0, 0};
@@ -585,7 +588,7 @@ static void *pass_run(void *arg)
     /* files and stdout, in pass order */
     pthread_mutex_lock(&R->mu);
     while (R->out_turn != ps->index && !R->failed) pthread_cond_wait(&R->cv, &R->mu);
-    const int skip = R->found || R->failed;
+    const int skip = R->found_pass < ps->index || R->failed;
     pthread_mutex_unlock(&R->mu);
     if (!skip) {
         if (!ps->live && ps->log.len) fputs(ps->log.buf, stdout);
@@ -616,7 +619,6 @@ static void *pass_run(void *arg)
         fflush(stdout);
     }
     pthread_mutex_lock(&R->mu);
-    if (found) R->found = 1;
     R->out_turn = ps->index + 1;
     pthread_cond_broadcast(&R->cv);
     pthread_mutex_unlock(&R->mu);
@@ -774,6 +776,7 @@ int main(int argc, char **argv)
     R.fr.D = gecm_s2_default_D(R.B1);
     R.fr.U = GECM_S2_DEFAULT_U;
     R.lcg = (uint64_t)(R.t_start * 1e6) * 0x9E3779B97F4A7C15ULL + (uint64_t)getpid();
+    R.found_pass = (size_t)-1;
 
     if (R.rd_pending) { pthread_join(R.rd_thread, NULL); R.rd_pending = 0; }
     if (!R.rd_rc && R.nranges == 1)                                                /* ecm.c:1139-1146 */
@@ -784,7 +787,7 @@ int main(int argc, char **argv)
         const int s = (int)(pi % (size_t)slots);
         if (running[s]) { pthread_join(pass[s].th, NULL); pass_release(&pass[s]); running[s] = 0; }
         pthread_mutex_lock(&R.mu);
-        const int stop = R.found || R.failed;
+        const int stop = R.found_pass != (size_t)-1 || R.failed;
         pthread_mutex_unlock(&R.mu);
         if (stop) break;
         pass_t *ps = &pass[s];
