@@ -15,6 +15,8 @@
  *   phase 2  gecm_stage2_init(work->D, work->U)
  *   phase 3  gecm_stage2_pair(pairmap_steps, pairmap_v, pairmap_u, work->amin) with the map the reference's own
  *            pair() made, accumulator back into work->stg2acc
+ * In the reference's special-form mode (isMersenne != 0) the context is made on mdata->n = 2^k -/+ 1 or 2^k - c as in
+ * every other mode; only the vectors differ there (plain residues instead of Montgomery forms) and are converted.
  *
  * The binary (oracle/_ref/avx-ecm-52-l1, git-ignored) travels to the GPU box; tests/test_gpu_dropin.py runs it and
  * compares the files it writes with the ones the pure reference wrote.
@@ -69,6 +71,28 @@ static gecm_ctx *ctx_of(thread_data_t *t, uint32_t tid)
     return g_ctx[tid];
 }
 
+/* The reference's special-form mode (mdata->isMersenne != 0: mdata->n is 2^k -/+ 1 or 2^k - c, main.c:642-684) keeps PLAIN
+ * residues in its vectors — ecm.c:1763-1772 skips the conversion to Montgomery form — where the ABI's vector operands
+ * are x * 2^MAXBITS mod n.  to_abi / from_abi multiply a whole vector by 2^MAXBITS or its inverse modulo mdata->n. */
+static void scale_vec(thread_data_t *t, bignum *v, int to_montgomery)
+{
+    mpz_t n, x, r;
+    mpz_inits(n, x, r, NULL);
+    extract_bignum_from_vec_to_mpz(n, t->mdata->n, 0, NWORDS);
+    mpz_set_ui(r, 1);
+    mpz_mul_2exp(r, r, MAXBITS);
+    mpz_mod(r, r, n);
+    if (!to_montgomery) mpz_invert(r, r, n);
+    for (int k = 0; k < VECLEN; k++) {
+        extract_bignum_from_vec_to_mpz(x, v, k, NWORDS);
+        mpz_mul(x, x, r);
+        mpz_mod(x, x, n);
+        for (uint32_t j = 0; j < NWORDS; j++) v->data[j * VECLEN + k] = 0;
+        insert_mpz_to_vec(v, x, k);
+    }
+    mpz_clears(n, x, r, NULL);
+}
+
 /* phase 0: ecm_build_curve_work_fcn (ecm.c:201-246) stays on the host, as in the reference; its output goes up */
 static void gpu_build_curve(void *vptr)
 {
@@ -76,7 +100,10 @@ static void gpu_build_curve(void *vptr)
     thread_data_t *ud = (thread_data_t *)tp->user_data;
     const uint32_t tid = (uint32_t)tp->tindex;
     g_ref_fcn[0](vptr);
+    const int plain = ud[tid].mdata->isMersenne != 0;
+    if (plain) { scale_vec(&ud[tid], ud[tid].P->X, 1); scale_vec(&ud[tid], ud[tid].P->Z, 1); scale_vec(&ud[tid], ud[tid].work->s, 1); }
     CHECK(gecm_upload_points(ctx_of(&ud[tid], tid), ud[tid].P->X->data, ud[tid].P->Z->data, ud[tid].work->s->data, VECLEN));
+    if (plain) { scale_vec(&ud[tid], ud[tid].P->X, 0); scale_vec(&ud[tid], ud[tid].P->Z, 0); scale_vec(&ud[tid], ud[tid].work->s, 0); }
     __sync_fetch_and_add(&g_calls[0], 1);
 }
 
@@ -90,7 +117,8 @@ static void gpu_stage1(void *vptr)
     const uint32_t range = P_MIN <= 2 ? 0u : (uint32_t)(P_MIN / 100000000ULL);       /* ecm.c:1215: rangemin */
     CHECK(gecm_stage1_range(c, STAGE1_MAX, range));
     CHECK(gecm_sync(c));
-    CHECK(gecm_download_points(c, ud[tid].P->X->data, ud[tid].P->Z->data));
+    if (ud[tid].mdata->isMersenne != 0) CHECK(gecm_download_points_plain(c, ud[tid].P->X->data, ud[tid].P->Z->data));
+    else CHECK(gecm_download_points(c, ud[tid].P->X->data, ud[tid].P->Z->data));
     gecm_stage1_stats st;
     gecm_get_stage1_stats(c, &st);
     ecm_work *w = ud[tid].work;
@@ -112,7 +140,8 @@ static void gpu_stage1(void *vptr)
  * the reference holds the gcd itself in that lane (ecm.c:1927-1939) */
 static void fetch_acc(gecm_ctx *c, ecm_work *w)
 {
-    CHECK(gecm_download_acc(c, w->stg2acc->data));
+    CHECK(gecm_download_acc(c, w->stg2acc->data));       /* Montgomery form also in special-form mode: the reference only
+                                                            takes its gcd with the input number, and 2^MAXBITS is a unit */
     for (int k = 0; k < VECLEN; k++) {
         char dec[2048];
         if (gecm_stage2_factor(c, (size_t)k, dec, sizeof dec, NULL) == 1) {

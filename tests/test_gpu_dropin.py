@@ -104,3 +104,24 @@ def test_reference_vececm_with_gpu_phases_at_baseline_size():
     assert res == c["results_lines"] and len(res) == 1
     assert "performed %d pt-adds, %d inversions, and %d pair-muls in stage 2" % tuple(c["stage2_counts"]) in out
     assert save == S1["T35_46"]["save_lines"]
+
+
+SPECIAL = {c["name"]: c for c in json.load(open(os.path.join(GOLDEN, "special.json")))}
+
+
+@pytest.mark.skipif(not os.path.exists(L1), reason="oracle/_ref/avx-ecm-52-l1 not built (needs /root/reference at build time)")
+@pytest.mark.parametrize("name", sorted(SPECIAL))
+def test_reference_vececm_with_gpu_phases_special_form_inputs(name):
+    """the reference's special-form mode (main.c:642-684: arithmetic modulo 2^k -/+ 1 or 2^k - c, vectors holding plain
+    residues, factors checked against the input number) through the same four phase functions: the binding makes the
+    context on mdata->n as always and converts the vectors at the seam (oracle/ref_gecm_l1_binding.c scale_vec)"""
+    c = SPECIAL[name]
+    out, save, res, calls = _run_l1(c)
+    assert calls[0] == calls[1] == 1
+    assert save == c["save_lines"]
+    assert res == c["results_lines"]
+    assert "with %d point-adds and %d point-doubles" % (c["ptadds"], c["ptdups"]) in out
+    assert "performed %d pt-adds, %d inversions, and %d pair-muls in stage 2" % tuple(c["stage2_counts"]) in out
+    for l in c["stdout_lines"]:
+        if l.startswith("Using special") or l.startswith("commencing"):
+            assert l in out
