@@ -376,10 +376,6 @@ static int row_a_lds(const gecm_dev *d)
 {
     const char *e = getenv("GECM_ROW_ALDS");
     if (e && e[0] >= '0' && e[0] <= '2' && !e[1]) return e[0] - '0';
-    /* three limbs per lane (above 868 bits): the crossbar variant wins at every batch size (4096 curves x 1023 bits, B1 = 1e5:
-     * 1074 ms against 1092, profiles/r03/rowp_lds_prefetch_ab_4096_curves.txt) — its 39 rows of 10 instructions hide the
-     * start-up latency that costs the shorter multiplies their gain */
-    if (d->row_nq >= 3) return 1;
     return d->stride > (size_t)d->cus * 16 ? 1 : GECM_ROW_DEFAULT_SMALL;
 }
 

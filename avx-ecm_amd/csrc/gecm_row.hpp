@@ -41,7 +41,21 @@ template <int NQ>
 struct RowMod {
     uint32_t n[NQ];   // this lane's limbs of the modulus
     uint32_t rho;     // -modulus^-1 mod 2^28 (unused when RHO1)
+    int32_t c16;      // 16, in a scalar register, opaque to the compiler (row_c16)
 };
+
+// An empty asm statement that READS x: a second use of the value stops the compiler from re-associating the sum it
+// belongs to (and moving its instruction) and it stays where it is written; no instruction, no register written.
+__device__ __forceinline__ void row_pin(const int64_t &x)
+{
+    asm volatile("" ::"v"(x));
+}
+__device__ __forceinline__ int32_t row_c16()
+{
+    int32_t c;
+    asm volatile("s_mov_b32 %0, 16" : "=s"(c));
+    return c;
+}
 
 #define GECM_DPP_ROW_SHL1 0x101        /* lane l <- lane l+1 of the row (lane 15: 0) */
 #define GECM_DPP_ROW_SHR1 0x111        /* lane l <- lane l-1 of the row (lane 0: 0) */
@@ -56,6 +70,11 @@ template <int I>
 __device__ __forceinline__ uint32_t row_bcast(uint32_t x)
 {
     return row_dpp<GECM_DPP_ROW_NEWBCAST + I>(x);
+}
+template <int I>
+__device__ __forceinline__ int64_t row_bcast64(int64_t x)       // two registers in one move (v_mov_b64_dpp)
+{
+    return __builtin_amdgcn_update_dpp((int64_t)0, x, GECM_DPP_ROW_NEWBCAST + I, 0xF, 0xF, true);
 }
 // every lane <- lane I of its row, through the LDS crossbar (ds_swizzle, bit mode: lane = (lane & 0x10) | I):
 // no VALU issue slot, the latency is covered by issuing all broadcasts of a multiply before its first row
@@ -118,10 +137,107 @@ __device__ __forceinline__ void fer_mul(FeR<NQ> &r, const FeR<NQ> &a, const FeR<
     // ALDS (3 or more wavefronts per SIMD hide the start-up latency): every limb by ds_swizzle, requested up front.
     static_assert(ROWS % NQ == 0 && ROWS <= 16 * NQ, "whole lanes, at most 16 of them");
     constexpr int ND = ALDS ? 0 : (GECM_ROW_DPP_ROWS < ROWS ? GECM_ROW_DPP_ROWS : ROWS);
+#ifndef GECM_ROW_OLD_NQ2
+    if constexpr ((NQ == 2 || NQ == 3) && !ALDS && ND == ROWS) {
+        // Two or three limbs per lane: the multiply-adds are written in C and the compiler places them (it knows how
+        // many instructions lie between a result and the DPP move that reads it; an asm statement counts as none and
+        // is padded).  Two things keep a row at 3 + 2 NQ multiply-adds and 3 DPP moves: the hand-over "16 x high
+        // part" multiplies by m.c16, a 16 the compiler cannot see through (it would otherwise spend a shift, a mask
+        // and a 64-bit add on it), and the slot the window shift has emptied starts from {lo, 0} as the addend of its
+        // first product.  Per row at NQ = 2: 8 VALU instructions and no s_nop where the round-2 form had 9 and two.
+        int64_t T[NQ];
+        // 4 x limb j of a in every lane of the row: limbs 0 and 1 of a lane travel as ONE 64-bit DPP move
+        // (v_mov_b64_dpp knows row_newbcast only, which is the one needed), limb 2 (NQ = 3) on its own
+        const int64_t a01 = (int64_t)(((uint64_t)(uint32_t)a4[1] << 32) | (uint32_t)a4[0]);
+        int64_t Ap = row_bcast64<0>(a01);
+        int32_t As = 0;
+        auto limb = [&](auto jc) -> int32_t {     // limb j, which the last request that covers it has brought
+            constexpr int q = decltype(jc)::value % NQ;
+            return q == 0 ? (int32_t)(uint32_t)Ap : q == 1 ? (int32_t)(Ap >> 32) : As;
+        };
+#pragma unroll
+        for (int t = 0; t < NQ; t++) T[t] = (int64_t)limb(IC<0>{}) * b4[t];
+        // The order inside a row is pinned (sched_barrier, row_pin): the digit broadcast and the window shift each read
+        // a result two instructions old, so no wait state is left to pad:
+        //   digit | q*n (lowest slot first) | a*b into the next lowest slot (and the middle one) | shift | hand-over
+        //   | a*b into the emptied slot | request for what the next row's products need
+        static_for<0, ROWS>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            constexpr int rot = i % NQ, nxt = (i + 1) % NQ;
+            const uint32_t Q = row_bcast<0>(RHO1 ? (uint32_t)T[rot] : (uint32_t)T[rot] * m.rho);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < NQ; t++) {
+                T[(t + rot) % NQ] = (int64_t)((uint64_t)T[(t + rot) % NQ] + (uint64_t)Q * m.n[t]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const int32_t Ac = limb(IC<i + 1>{});                  // row i adds limb i + 1 of a
+            if constexpr (i + 1 < ROWS) {
+#pragma unroll
+                for (int t = 0; t < NQ - 1; t++) {
+                    T[(t + nxt) % NQ] += (int64_t)Ac * b4[t];
+                    row_pin(T[(t + nxt) % NQ]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            const int32_t hi = (int32_t)(T[rot] >> 32);
+            const uint32_t lo = row_dpp<GECM_DPP_ROW_SHL1>((uint32_t)T[rot]);
+            __builtin_amdgcn_sched_barrier(0);
+            T[nxt] += (int64_t)hi * m.c16;
+            row_pin(T[nxt]);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (i + 1 < ROWS) {
+                T[rot] = (int64_t)Ac * b4[NQ - 1] + (int64_t)(uint64_t)lo;
+                row_pin(T[rot]);
+            } else {
+                T[rot] = (int64_t)(uint64_t)lo;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (i + 2 < ROWS) {
+                if constexpr ((i + 2) % NQ == 0) Ap = row_bcast64<(i + 2) / NQ>(a01);
+                else if constexpr ((i + 2) % NQ == 2) As = (int32_t)row_bcast<(i + 2) / NQ>((uint32_t)a4[NQ - 1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        });
+        int32_t lo[NQ];
+        int64_t carry = 0;
+#pragma unroll
+        for (int t = 0; t < NQ - 1; t++) {
+            const int64_t u = (T[(t + ROWS) % NQ] >> 4) + carry + (1 << 27);
+            carry = u >> GECM_LIMB_BITS;
+            lo[t] = (int32_t)((uint32_t)u & GECM_LIMB_MASK) - (1 << 27);
+        }
+        const int32_t ut = (int32_t)(T[(NQ - 1 + ROWS) % NQ] >> 4) + (int32_t)carry + (1 << 27);
+        lo[NQ - 1] = (int32_t)((uint32_t)ut & GECM_LIMB_MASK) - (1 << 27);
+        const int32_t below = (int32_t)row_dpp<GECM_DPP_ROW_SHR1>((uint32_t)(ut >> GECM_LIMB_BITS));
+        r.v[0] = lo[0] + below;
+#pragma unroll
+        for (int t = 1; t < NQ; t++) r.v[t] = lo[t];
+        return;
+    }
+#endif
     int32_t Ab[ROWS];
+#ifndef GECM_ROW_NO_PAIR_BCAST
+    // One limb per lane, all rows by DPP: the limbs travel TWO per move.  Every lane first takes the limb of the lane
+    // above next to its own (one row_shl:1 per multiply); a 64-bit move (v_mov_b64_dpp, row_newbcast — the one control
+    // it knows) from lane 2k then brings limbs 2k and 2k + 1: 8 moves + 1 instead of 16 for the 416-bit class.
+    constexpr bool PAIRS = NQ == 1 && !ALDS && ND == ROWS;
+    int64_t a01 = 0;
+    if constexpr (PAIRS)
+        a01 = (int64_t)(((uint64_t)row_dpp<GECM_DPP_ROW_SHL1>((uint32_t)a4[0]) << 32) | (uint32_t)a4[0]);
+#else
+    constexpr bool PAIRS = false;
+    const int64_t a01 = 0;
+#endif
     auto request = [&](auto jc) {
         constexpr int j = decltype(jc)::value;
-        if constexpr (j < ND) Ab[j] = (int32_t)row_bcast<j / NQ>((uint32_t)a4[j % NQ]);
+        if constexpr (PAIRS) {
+            if constexpr (j < ROWS && j % 2 == 0) {
+                const int64_t P = row_bcast64<j>(a01);
+                Ab[j] = (int32_t)(uint32_t)P;
+                if constexpr (j + 1 < ROWS) Ab[j + 1] = (int32_t)(P >> 32);
+            }
+        } else if constexpr (j < ND) Ab[j] = (int32_t)row_bcast<j / NQ>((uint32_t)a4[j % NQ]);
         else if constexpr (j < ROWS) Ab[j] = (int32_t)row_bcast_lds<j / NQ>((uint32_t)a4[j % NQ]);
     };
     // slot plan: row i < ND: first place = DPP request for row i+1 (if that is a DPP row) else one LDS request;
@@ -681,6 +797,11 @@ __device__ __forceinline__ void stage1_row(const uint32_t *__restrict__ tape, ui
     (void)slots_;
 #endif
     constexpr bool ALDS = BC == 1;
+#ifdef GECM_ROW_PRIO
+    // experiment (tools/build_row_variant.sh): with 8 wavefronts per workgroup, wavefronts w and w + 4 share a SIMD;
+    // give one of each pair a higher issue priority so that it runs as if alone and the other fills its gaps
+    if ((threadIdx.x >> 8) & 1u) __builtin_amdgcn_s_setprio(GECM_ROW_PRIO);
+#endif
     const uint32_t cidx = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;      // wavefronts of a workgroup are independent
     const uint32_t l = threadIdx.x & 15u;
     const bool isZ = (threadIdx.x & 16u) != 0;
@@ -698,6 +819,7 @@ __device__ __forceinline__ void stage1_row(const uint32_t *__restrict__ tape, ui
     }
     mp.rho = 1u;
     mn.rho = rho_n;
+    mp.c16 = mn.c16 = row_c16();
     PtR<NQ> P;
     FeR<NQ> s4, t;
     fer_load<NQ>(t, mine, stride, cidx, l, nl);

@@ -69,7 +69,7 @@ def test_config_4096_curves_b1_1e6(name, other):
 def test_config4_4096_curves_1023_bits_32_bit_boundary_b1_1e5():
     """BASELINE configs[4]: the DIGITBITS = 32 boundary (NWORDS = 32, MAXBITS = 1024), 1023-bit N, B1 = 1e5, the whole
     4096-curve batch: one sha256 over all save lines through the layout the library picks (32 lanes per curve, three
-    limbs per lane, the crossbar variant) and through eight lanes per curve; the first 16 lanes against the lines the
+    limbs per lane, operand limbs by DPP — two per 64-bit move) and through eight lanes per curve; the first 16 lanes against the lines the
     reference's 32-bit build wrote; lanes 0, 63, 64, 4095 against the oracle in the 32-bit format"""
     import pyecm
     case = S1["n1023_d32_b1_100000"]
@@ -87,7 +87,7 @@ def test_config4_4096_curves_1023_bits_32_bit_boundary_b1_1e5():
         got = eng.save_lines()
         sha[used] = hashlib.sha256("".join(got).encode()).hexdigest()
         if lanes == 0:
-            assert used == 32 and eng.last_kernel_name() == "k_stage1_row<3, 39, true>"
+            assert used == 32 and eng.last_kernel_name() == "k_stage1_row<3, 39, false>"
             lines = got
             assert (eng.stage1_stats().ptadds, eng.stage1_stats().ptdups) == (case["ptadds"], case["ptdups"]) == (195448, 23269)
     eng.close()

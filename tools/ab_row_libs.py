@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Interleaved A/B of the 32-lane stage-1 kernel between shared libraries (GECM_LIB), separate processes on the same
-GPU box: 4096 curves, B1 = 1e5, three passes each (the first discarded), repeated three times; save lines compared.
+GPU box: 4096 curves (AB_CURVES=n for another batch), B1 = 1e5, three passes each (the first discarded), repeated three
+times; save lines compared.
 usage: ab_row_libs.py libA.so libB.so@2 ... [-- bits ...]      (lib@m: GECM_ROW_ALDS=m, the operand-broadcast variant)"""
 import hashlib, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,7 +14,7 @@ n = random.Random(bits).getrandbits(bits) | (1 << (bits - 1)) | 1
 eng = pyecm.Engine(n)
 out = []
 for _ in range(3):
-    eng.build_curves(list(range(1000, 1000 + 4096)))
+    eng.build_curves(list(range(1000, 1000 + int(os.environ.get('AB_CURVES', '4096')))))
     eng.stage1(100000)
     out.append(eng.last_kernel_ms())
 print(out[1:], hashlib.sha256("".join(eng.save_lines()[::16]).encode()).hexdigest()[:12], eng.lanes_per_curve())
