@@ -376,6 +376,11 @@ static int row_a_lds(const gecm_dev *d)
 {
     const char *e = getenv("GECM_ROW_ALDS");
     if (e && e[0] >= '0' && e[0] <= '2' && !e[1]) return e[0] - '0';
+    /* two or three limbs per lane: the DPP rows (operand limbs two per v_mov_b64_dpp, gecm_row.hpp) beat the crossbar
+     * variant by 8-12 % at every batch size from 4096 to 16,384 curves (profiles/r03/mid_batch_rows.txt); one limb per
+     * lane: DPP up to two wavefronts per SIMD (4096 curves: 262 against 284 ms), the crossbar from there (6144: 363
+     * against 373; equal from 8192 on) */
+    if (d->row_nq >= 2) return 0;
     return d->stride > (size_t)d->cus * 16 ? 1 : GECM_ROW_DEFAULT_SMALL;
 }
 
