@@ -199,15 +199,18 @@ __device__ __forceinline__ void fer_mul(FeR<NQ> &r, const FeR<NQ> &a, const FeR<
                 __builtin_amdgcn_sched_barrier(0);
             }
         });
+        // balanced normalisation as below, in the accumulators' own scale: u16 = 16 x (value + carry + 2^27) has the limb
+        // (+ 2^27) in bits 4..31 of its low register and the carry AS its high register
         int32_t lo[NQ];
-        int64_t carry = 0;
+        int32_t carry = 0;
 #pragma unroll
         for (int t = 0; t < NQ - 1; t++) {
-            const int64_t u = (T[(t + ROWS) % NQ] >> 4) + carry + (1 << 27);
-            carry = u >> GECM_LIMB_BITS;
-            lo[t] = (int32_t)((uint32_t)u & GECM_LIMB_MASK) - (1 << 27);
+            int64_t u16 = T[(t + ROWS) % NQ] + (int64_t)(1u << 31);
+            if (t > 0) u16 += (int64_t)carry * m.c16;
+            carry = (int32_t)(u16 >> 32);
+            lo[t] = (int32_t)(((uint32_t)u16 >> 4) & GECM_LIMB_MASK) - (1 << 27);
         }
-        const int32_t ut = (int32_t)(T[(NQ - 1 + ROWS) % NQ] >> 4) + (int32_t)carry + (1 << 27);
+        const int32_t ut = (int32_t)(T[(NQ - 1 + ROWS) % NQ] >> 4) + carry + (1 << 27);
         lo[NQ - 1] = (int32_t)((uint32_t)ut & GECM_LIMB_MASK) - (1 << 27);
         const int32_t below = (int32_t)row_dpp<GECM_DPP_ROW_SHR1>((uint32_t)(ut >> GECM_LIMB_BITS));
         r.v[0] = lo[0] + below;
