@@ -231,7 +231,8 @@ extern "C" int gecm_dev_device_name(gecm_dev *d, char *buf, size_t len)
 {
     hipDeviceProp_t p;
     HIPCHK(hipGetDeviceProperties(&p, d->device));
-    snprintf(buf, len, "%s (%s, %d CUs)", p.name, p.gcnArchName, p.multiProcessorCount);
+    /* (some boxes report an empty marketing name) */
+    snprintf(buf, len, "%s (%s, %d CUs)", p.name[0] ? p.name : "AMD GPU", p.gcnArchName, p.multiProcessorCount);
     return 0;
 }
 
