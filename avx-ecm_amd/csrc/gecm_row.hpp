@@ -96,6 +96,12 @@ __device__ __forceinline__ void umad(int64_t &acc, uint32_t x, uint32_t y)
 {
     asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(x), "v"(y) : "vcc");
 }
+__device__ __forceinline__ int64_t smad0(int32_t x, int32_t y)       // x * y
+{
+    int64_t r;
+    asm("v_mad_i64_i32 %0, vcc, %1, %2, 0" : "=v"(r) : "v"(x), "v"(y) : "vcc");
+    return r;
+}
 __device__ __forceinline__ int64_t smad16(int32_t x, int64_t add)    // 16 * x + add
 {
     int64_t r;
@@ -259,7 +265,10 @@ __device__ __forceinline__ void fer_mul(FeR<NQ> &r, const FeR<NQ> &a, const FeR<
         constexpr int first_lds = (i + 1 < ND) ? 0 : 1;
         constexpr int before = ND + 2 * i + (i >= ND ? i - ND + 1 : 0);
         // (the multiply-add into the lowest slot was fused with the previous row's hand-over, except in row 0)
-        if constexpr (i == 0) smad(T[rot], Ab[0], b4[0]);
+        if constexpr (i == 0) {
+            if constexpr (NQ == 1) T[0] = smad0(Ab[0], b4[0]);
+            else smad(T[rot], Ab[0], b4[0]);
+        }
 #pragma unroll
         for (int t = 1; t < NQ; t++) smad(T[(t + rot) % NQ], Ab[i], b4[t]);
         if constexpr (!ALDS) {
@@ -292,6 +301,14 @@ __device__ __forceinline__ void fer_mul(FeR<NQ> &r, const FeR<NQ> &a, const FeR<
     // balanced normalisation.  Inside the lane the slots still hold whole column sums (only the lowest slot is
     // folded per row), so the carry runs through them in 64 bits; the top slot is a fresh 28-bit hand-over, so
     // what leaves the lane is small and goes to the lane above carry-save: limb = centred low 28 bits + carry.
+    if constexpr (NQ == 1) {
+        // in the accumulator's own scale: u16 = 16 x (value + 2^27) has the limb (+ 2^27) in bits 4..31 of its low register
+        // and what leaves the lane AS its high register; the neighbour's carry comes in on the add itself (DPP)
+        const int64_t u16 = T[0] + (int64_t)(1u << 31);
+        const int32_t lim = (int32_t)(((uint32_t)u16 >> 4) & GECM_LIMB_MASK) - (1 << 27);
+        r.v[0] = lim + (int32_t)row_dpp<GECM_DPP_ROW_SHR1>((uint32_t)(u16 >> 32));
+        return;
+    }
     int32_t lo[NQ];
     int64_t carry = 0;
 #pragma unroll
