@@ -8,7 +8,7 @@
 // (gecm_quad.hpp) leaves half of the SIMDs without a wavefront and the other half at the slow rate.
 //
 // The multiply is row-wise (operand scanning) Montgomery, as in the eight-lane layout, re-thought so that a row
-// costs 3 multiply-adds and 3 DPP moves per lane at NQ = 1 (5 + 3 at NQ = 2):
+// costs 3 multiply-adds and 2.5 DPP moves per lane at NQ = 1 (5 + 2.5 at NQ = 2, 7 + 2.67 at NQ = 3):
 //   * arithmetic is modulo N' = m*N with N' = -1 (mod 2^28), so the Montgomery digit is the low limb itself
 //     (rho = 1: no multiplication on the dependent path); N' is 28 bits longer than N, which is exactly the room
 //     16 lanes x 28 bits leave above a 415-bit N plus the 5 bits of lazy-reduction headroom;
@@ -16,8 +16,10 @@
 //     low register IS the low limb (times 16): no shift or mask instructions; the operands are pre-multiplied by
 //     4 each, the digit is used as it comes (times 16), and the hand-over "high part into the next slot" is one
 //     more v_mad (x16);
-//   * digit and operand limbs are broadcast inside the row by DPP row_newbcast, the window moves down by DPP
-//     row_shl:1;
+//   * digit and operand limbs are broadcast inside the row by DPP row_newbcast — the operand limbs TWO per move
+//     (v_mov_b64_dpp, which knows exactly this control) —, the window moves down by DPP row_shl:1;
+//   * a multiply ends in the accumulators' own scale: T + 2^31 holds the balanced limb (+ 2^27) in bits 4..31 of its
+//     low register and the carry for the lane above AS its high register;
 //   * limbs are SIGNED and balanced ([-2^27, 2^27] after a multiply): subtraction is limb-wise without a bias,
 //     and the pre-multiplied operands stay inside 32 bits.
 // The residues are the same elements of Z/N as in every other layout (N | N'), so results are identical; the
@@ -121,8 +123,8 @@ __device__ __forceinline__ int64_t smad16_smad(int32_t x, int64_t add, int32_t y
 // r = a*b/R' mod (modulus of m), R' = 2^(28*ROWS): ROWS = the limbs in use (a multiple of NQ, at most 16*NQ; limbs
 // from ROWS up are zero in every operand and in the modulus, so their rows would add nothing).  Operand limbs |.| < 2^29; result limbs in [-2^27-4, 2^27+4]
 // (top limb: whatever the value needs), |result| < |a||b|/R' + modulus.
-// ALDS: the limbs of a are broadcast through the LDS crossbar (ds_swizzle: no VALU issue slot, best from 3 wavefronts
-// per SIMD up) instead of DPP row_newbcast (which sits in a wait state the digit broadcast needs anyway: best at 2).
+// ALDS: the limbs of a are broadcast through the LDS crossbar (ds_swizzle: no VALU issue slot; with ONE limb per lane best
+// from 3 wavefronts per SIMD up) instead of DPP row_newbcast (best at 2, and at every batch size with 2-3 limbs per lane).
 template <int NQ, int ROWS, bool RHO1, bool ALDS>
 __device__ __forceinline__ void fer_mul(FeR<NQ> &r, const FeR<NQ> &a, const FeR<NQ> &b, const RowMod<NQ> &m)
 {
