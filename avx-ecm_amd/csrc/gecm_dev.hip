@@ -171,7 +171,7 @@ extern "C" int gecm_dev_open(gecm_dev **out, int device, int nl, const uint32_t 
 extern "C" int gecm_dev_set_rowconst(gecm_dev *d, int nq, int rows, const uint32_t *words)
 {
     HIPCHK(hipSetDevice(d->device));
-    if (nq < 1 || nq > GECM_ROW_MAXNQ || 16 * nq > GECM_ROW_WORDS || rows < 1 || rows > 16 * nq || rows % nq) {
+    if (nq < 1 || nq > GECM_ROW_MAXNQ || 16 * nq > GECM_ROW_WORDS || rows <= 16 * (nq - 1) || rows > 16 * nq) {
         g_err = "gecm_dev_set_rowconst: limbs per lane out of range";
         return -2;
     }

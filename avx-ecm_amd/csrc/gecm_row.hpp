@@ -143,10 +143,13 @@ __device__ __forceinline__ void fer_mul(FeR<NQ> &r, const FeR<NQ> &a, const FeR<
     //   * rows ND .. get theirs by ds_swizzle through the LDS crossbar (no VALU issue slot, but ~70 cycles), all
     //     requested in the slots of the first rows.
     // ALDS (3 or more wavefronts per SIMD hide the start-up latency): every limb by ds_swizzle, requested up front.
-    static_assert(ROWS % NQ == 0 && ROWS <= 16 * NQ, "whole lanes, at most 16 of them");
+    static_assert(ROWS > 16 * (NQ - 1) && ROWS <= 16 * NQ, "the limbs in use fill the lanes but for the last one");
     constexpr int ND = ALDS ? 0 : (GECM_ROW_DPP_ROWS < ROWS ? GECM_ROW_DPP_ROWS : ROWS);
 #ifndef GECM_ROW_OLD_NQ2
-    if constexpr ((NQ == 2 || NQ == 3) && !ALDS && ND == ROWS) {
+    // (ROWS need not be a multiple of NQ here — 31 rows for 831 bits, 38 for 1023 —; the crossbar variant below wants whole
+    // lanes, so a shape with a partly used last lane runs these rows whatever ALDS says)
+    constexpr bool CROWS = (NQ == 2 || NQ == 3) && ((!ALDS && ND == ROWS) || ROWS % NQ != 0);
+    if constexpr (CROWS) {
         // Two or three limbs per lane: the multiply-adds are written in C and the compiler places them (it knows how
         // many instructions lie between a result and the DPP move that reads it; an asm statement counts as none and
         // is padded).  Two things keep a row at 3 + 2 NQ multiply-adds and 3 DPP moves: the hand-over "16 x high
@@ -228,6 +231,9 @@ __device__ __forceinline__ void fer_mul(FeR<NQ> &r, const FeR<NQ> &a, const FeR<
     }
 #endif
     int32_t Ab[ROWS];
+#ifndef GECM_ROW_OLD_NQ2
+    static_assert(CROWS || ROWS % NQ == 0, "these rows rotate the slots back to where they started: whole lanes");
+#endif
 #ifndef GECM_ROW_NO_PAIR_BCAST
     // One limb per lane, all rows by DPP: the limbs travel TWO per move.  Every lane first takes the limb of the lane
     // above next to its own (one row_shl:1 per multiply); a 64-bit move (v_mov_b64_dpp, row_newbcast — the one control

@@ -87,7 +87,7 @@ def test_config4_4096_curves_1023_bits_32_bit_boundary_b1_1e5():
         got = eng.save_lines()
         sha[used] = hashlib.sha256("".join(got).encode()).hexdigest()
         if lanes == 0:
-            assert used == 32 and eng.last_kernel_name() == "k_stage1_row<3, 39, false>"
+            assert used == 32 and eng.last_kernel_name() == "k_stage1_row<3, 38, false>"
             lines = got
             assert (eng.stage1_stats().ptadds, eng.stage1_stats().ptdups) == (case["ptadds"], case["ptdups"]) == (195448, 23269)
     eng.close()
